@@ -1,0 +1,218 @@
+/* hrseg.h -- C ABI of libhrseg_hip.so: the MI355X (gfx950) kernels behind the
+ * hierarchical-segmentation train-step hot path.
+ *
+ * The reference (Banksylel/Restrictive-Hierarchical-Semantic-Segmentation) has
+ * no FFI layer: its hot path is eager PyTorch ops called from
+ * Models/models.py, Metrics/losses.py, Metrics/performance_metrics.py and
+ * train.py.  Each entry point below replaces the PyTorch/cuDNN op(s) cited
+ * next to it; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the
+ *     caller (PyTorch's caching allocator); the library allocates nothing and
+ *     keeps no state besides a thread-local error string.
+ *   - activations are NHWC fp32, addressed as pixel*ld + channel ("ld" =
+ *     floats per pixel row, >= C, multiple of 4) so a kernel can read or
+ *     write a channel slice of a wider tensor (concat without a copy).
+ *   - conv weights are OHWI fp32 = torch channels_last storage of the
+ *     reference's [Cout,Cin,kh,kw] parameter.
+ *   - logits / probabilities / targets at the API boundary are NCHW fp32
+ *     contiguous, as the reference returns them.
+ *   - all launches go to `stream` (a hipStream_t); no call synchronises.
+ *   - return 0 on success, a negative hrseg_status otherwise;
+ *     hrseg_last_error_string() describes the last failure on this thread.
+ */
+#ifndef HRSEG_H
+#define HRSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hrseg_stream_t; /* hipStream_t */
+
+enum hrseg_status {
+  HRSEG_OK = 0,
+  HRSEG_ERR_INVALID_ARG = -1,
+  HRSEG_ERR_LAUNCH = -2,
+  HRSEG_ERR_UNSUPPORTED = -3,
+};
+
+const char* hrseg_last_error_string(void);
+int hrseg_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Replaces nn.Conv2d as used at Models/models.py:113,116 (UNet 3x3+bias),
+ * :322-324 conv3x3, :364-370 Bottleneck 1x1/3x3, :483-511 fuse 1x1 / 3x3 s2,
+ * :579-582 stem, :614 shared_head 1x1, :656 downsample, :690,:701 transitions.
+ * k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Cin, Cout multiples of 16
+ * (implicit GEMM on v_mfma_f32_16x16x4_f32) except the stem-style Cin<=4 layer,
+ * which hrseg_conv_fwd/wgrad route to direct kernels.                        */
+typedef struct {
+  int B, Hi, Wi, Cin, ldx; /* input  x[B,Hi,Wi,Cin], row stride ldx   */
+  int Ho, Wo, Cout, ldy;   /* output y[B,Ho,Wo,Cout], row stride ldy  */
+  int ksize, stride;       /* 1 or 3 ; 1 or 2                          */
+} hrseg_conv_shape_t;
+
+/* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */
+int hrseg_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                   const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* dx = conv_transpose(dy, w) (+ dx if accumulate).  wt: [Cin][k*k][Cout]
+ * (hrseg_weight_transpose of w).  Shape as the forward conv's. */
+int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int accumulate,
+                     const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* dw += x (*) dy  (fp32 atomics; dw is [Cout][k*k][Cin] and must hold the
+ * running gradient, zeroed by the caller at the start of a step). */
+int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
+                     const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* wt[ci][t][co] = w[co][t][ci] */
+int hrseg_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin,
+                           hrseg_stream_t stream);
+
+/* ------------------------------------------------------------------ batch norm
+ * Replaces nn.BatchNorm2d / SyncBatchNorm-without-process-group in training
+ * mode (Models/models.py:114,117; bn_helper.py:4-11; BN_MOMENTUM :318) fused
+ * with the ReLU / residual add that follows it (:115,118,345,353-354,542).   */
+/* per-channel partial sums of y and y*y over pixel chunks -> partial[nchunks][2][C] (double) */
+int hrseg_bn_stats(const float* y, int ldy, long npix, int C, double* partial, int nchunks,
+                   hrseg_stream_t stream);
+/* reduce partials; write mean,rstd,scale,shift ([4][C] fp32 in `coef`); update
+ * running stats (momentum, unbiased var) and ++num_batches_tracked if given. */
+int hrseg_bn_finalize(const double* partial, int nchunks, long npix, int C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps, float* coef,
+                      hrseg_stream_t stream);
+/* eval mode: coef from running stats */
+int hrseg_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* coef,
+                       hrseg_stream_t stream);
+/* z = relu?( y*scale + shift (+ residual) ) */
+int hrseg_bn_apply(const float* y, int ldy, const float* coef, const float* residual, int ldr,
+                   int relu, float* z, int ldz, long npix, int C, hrseg_stream_t stream);
+/* backward, phase 1: g = dz * (z>0 if relu); partial sums of g and g*xhat */
+int hrseg_bn_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, int relu,
+                        const float* y, int ldy, const float* coef, long npix, int C,
+                        double* partial, int nchunks, hrseg_stream_t stream);
+/* backward, phase 2: dgamma += sum g*xhat, dbeta += sum g (if not NULL);
+ * dy = gamma*rstd*(g - mean_g - xhat*mean_gx); optionally dres (+)= g.
+ * `sums` is scratch [2][C] fp32 filled here from the partials. */
+int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int lddz,
+                       const float* z, int ldz, int relu, const float* y, int ldy,
+                       const float* coef, const float* gamma, float* dgamma, float* dbeta,
+                       float* dy, int lddy, float* dres, int lddres, int dres_accumulate,
+                       long npix, int C, int eval_mode, hrseg_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling / resampling / glue
+ * nn.MaxPool2d(2) (models.py:140); bilinear align_corners=True resize
+ * (nn.Upsample :156, F.interpolate :536-539,:746,:757,:766,:776) incl. the
+ * zero pad of `up` (:166-170) and the channel concat (:172,:747).            */
+int hrseg_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int B, int Hi, int Wi, int C,
+                       hrseg_stream_t stream);
+int hrseg_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
+                       int accumulate, int B, int Hi, int Wi, int C, hrseg_stream_t stream);
+/* out[b, py+oy, px+ox, :] (op)= bilinear(in)[oy,ox]; region outside the
+ * placed image is zero-filled when !accumulate. out image is Hout x Wout,
+ * the resized image Hr x Wr placed at (py,px). relu applied after the add. */
+int hrseg_bilinear_fwd(const float* in, int ldin, int B, int Hi, int Wi, int C, float* out,
+                       int ldout, int Hout, int Wout, int Hr, int Wr, int py, int px,
+                       int align_corners, int accumulate, int relu, hrseg_stream_t stream);
+int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, int Wi, int C, float* din,
+                       int lddin, int Hout, int Wout, int Hr, int Wr, int py, int px,
+                       int align_corners, int accumulate, hrseg_stream_t stream);
+/* out = relu?(a + b) ; strided channel copy ; masked relu backward */
+int hrseg_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int relu,
+              long npix, int C, hrseg_stream_t stream);
+int hrseg_copy(const float* in, int ldin, float* out, int ldout, int accumulate, long npix, int C,
+               hrseg_stream_t stream);
+int hrseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz, float* dx, int lddx,
+                   long npix, int C, hrseg_stream_t stream);
+int hrseg_nchw_to_nhwc(const float* in, float* out, int ldout, int B, int C, int H, int W,
+                       hrseg_stream_t stream);
+int hrseg_nhwc_to_nchw(const float* in, int ldin, float* out, int B, int C, int H, int W,
+                       hrseg_stream_t stream);
+
+/* ------------------------------------------------------------------ FiLM + heads + composition
+ * FiLM (models.py:58-77), outconv / classifier 1x1 heads (:180,:626-645),
+ * sigmoid / grouped-softmax probability composition (:266-304,:763-798).     */
+/* cond[b,c] = mean_{h,w} P[b,c,h,w]  (NCHW in); scratch: BC*64 doubles */
+int hrseg_gap_nchw(const float* p, float* cond, double* scratch, int BC, long hw,
+                   hrseg_stream_t stream);
+/* gb[b, 0:2F] = cond[b,:] @ Wl^T + bl   (Wl: [2F][Cc]) */
+int hrseg_film_linear_fwd(const float* cond, const float* wl, const float* bl, float* gb, int B,
+                          int Cc, int F2, hrseg_stream_t stream);
+/* dcond = dcond_scale * dgb @ Wl (written); dWl += dgb^T cond; dbl += sum_b dgb */
+int hrseg_film_linear_bwd(const float* cond, const float* wl, const float* dgb, float* dcond,
+                          float* dwl, float* dbl, int B, int Cc, int F2, float dcond_scale,
+                          hrseg_stream_t stream);
+/* head: z[b,pix,c] = sum_k W[c][k]*(f[b,pix,k]*gamma[b,k]+beta[b,k]) + bias[c];
+ * gb = [B][2F] (gamma | beta) or NULL for no FiLM; z is NHWC with row stride
+ * ldz; Cout <= 8. */
+int hrseg_head_fwd(const float* f, int ldf, const float* gb, const float* w, const float* bias,
+                   float* z, int ldz, int B, long hw, int F, int Cout, hrseg_stream_t stream);
+/* backward of the head: df (=|+=) gamma*(W^T dz) (df may be NULL); dW, dbias +=
+ * (atomics); dgb[b] += (sum_pix f*(W^T dz) | sum_pix W^T dz) when gb != NULL */
+int hrseg_head_bwd(const float* f, int ldf, const float* gb, const float* w, const float* dz,
+                   int lddz, float* df, int lddf, int df_accumulate, float* dw, float* dbias,
+                   float* dgb, int B, long hw, int F, int Cout, hrseg_stream_t stream);
+/* logits resize: NHWC low-res [B,Hi,Wi,C<=16] -> NCHW [B,C,Ho,Wo] bilinear
+ * (F.interpolate at models.py:757,766,776) and its transpose */
+int hrseg_logits_up_fwd(const float* in, int ldin, int B, int Hi, int Wi, int C, float* out, int Ho,
+                        int Wo, int align_corners, hrseg_stream_t stream);
+int hrseg_logits_up_bwd(const float* dout, int B, int Hi, int Wi, int C, float* din, int lddin,
+                        int Ho, int Wo, int align_corners, hrseg_stream_t stream);
+/* P0 = sigmoid(z0) ; NCHW */
+int hrseg_sigmoid_fwd(const float* z, float* p, long n, hrseg_stream_t stream);
+/* level L>0: groups given as parent channel index + child count per group
+ * (group_parent / group_size are HOST arrays, copied into the launch) */
+int hrseg_compose_fwd(const float* z, const float* pprev, float* p, int B, int C, int Cprev,
+                      long hw, int ngroups, const int* group_parent, const int* group_size,
+                      hrseg_stream_t stream);
+/* backward through composition: inputs dP (strided: element (b,c,i) at
+ * b*sb + c*sc + i*si, so a broadcast GAP gradient needs no materialisation),
+ * outputs dz (NCHW, accumulate flag) and dPprev (NCHW, accumulate flag). */
+int hrseg_compose_bwd(const float* dp, long sb, long sc, long si, const float* z,
+                      const float* pprev, float* dz, int dz_accumulate, float* dpprev,
+                      int dpprev_accumulate, int B, int C, int Cprev, long hw, int ngroups,
+                      const int* group_parent, const int* group_size, hrseg_stream_t stream);
+int hrseg_sigmoid_bwd(const float* dp, long sb, long sc, long si, const float* z, float* dz,
+                      int accumulate, int B, int C, long hw, hrseg_stream_t stream);
+
+/* ------------------------------------------------------------------ loss + metrics
+ * CrossEntropyLoss / SoftDiceLoss (Metrics/losses.py:16-134), consistency
+ * (:150-177), prediction prep + confusion counts (train.py:206-231,
+ * Metrics/performance_metrics.py:27-141).                                    */
+/* partial[b][c][5] += {n, sum t*logp, sum p*t, sum p, sum t} over t!=-1 (double) */
+int hrseg_loss_partials(const float* z, const float* t, double* partial, int B, int C, long hw,
+                        hrseg_stream_t stream);
+/* out[0]=ce, out[1]=dice, out[2]=dice_valid_count; coef[b][c][4] for the backward */
+int hrseg_loss_finalize(const double* partial, const float* w, int B, int C, float* out,
+                        float* coef, hrseg_stream_t stream);
+/* dz (=|+=) g_ce*dCE/dz + g_dice*dDice/dz ; g = device pointer to {g_ce,g_dice} */
+int hrseg_loss_bwd(const float* z, const float* t, const float* coef, const float* g, float* dz,
+                   int accumulate, int B, int C, long hw, hrseg_stream_t stream);
+/* sum |sum_{c in group} P[b,c] - Pprev[b,parent]| per group -> out[ngroups] (double, +=) */
+int hrseg_consistency(const float* p, const float* pprev, double* out, int B, int C, int Cprev,
+                      long hw, int ngroups, const int* group_parent, const int* group_size,
+                      hrseg_stream_t stream);
+/* argmax one-hot of z masked by t!=-1, plus confusion matrix counts
+ * cm[(C+child)*(C+child)] (int64, +=) of (target label, predicted label) with
+ * the synthetic background class 0 for child levels. mask_pred=1 is the train
+ * loop (predictions/targets zeroed where t==-1), 0 the test loop (z holds
+ * probabilities, raw targets). onehot may be NULL. */
+int hrseg_predict_metrics(const float* z, const float* t, float* onehot, long long* cm, int B,
+                          int C, long hw, int child, int mask_pred, hrseg_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.AdamW (train.py:513-516) over one flat fp32 parameter buffer. */
+int hrseg_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, float bc1, float bc2, float gscale,
+                hrseg_stream_t stream);
+int hrseg_fill(float* p, float v, long n, hrseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRSEG_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libhrseg_hip.so (the C ABI declared in include/hrseg.h).
+
+There is no fallback: if the shared library is missing the import of any
+product module fails with a clear error (build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C restrictive-hierarchical-semantic-segmentation_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhrseg_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the MI355X HIP library is not built. "
+        "Run `make -C restrictive-hierarchical-semantic-segmentation_amd/csrc` (needs hipcc); "
+        "there is no CPU fallback for the product path.")
+
+_lib = C.CDLL(LIB_PATH)
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_long
+_f = C.c_float
+
+
+class ConvShape(C.Structure):
+    """hrseg_conv_shape_t"""
+    _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride")]
+
+
+# name -> argtypes, exactly the prototypes of include/hrseg.h
+PROTOTYPES = {
+    "hrseg_conv_fwd": [_p, _p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_conv_dgrad": [_p, _p, _p, _i, C.POINTER(ConvShape), _p],
+    "hrseg_conv_wgrad": [_p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_weight_transpose": [_p, _p, _i, _i, _i, _p],
+    "hrseg_bn_stats": [_p, _i, _l, _i, _p, _i, _p],
+    "hrseg_bn_finalize": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p],
+    "hrseg_bn_eval_coef": [_p, _p, _p, _p, _f, _i, _p, _p],
+    "hrseg_bn_apply": [_p, _i, _p, _p, _i, _i, _p, _i, _l, _i, _p],
+    "hrseg_bn_bwd_reduce": [_p, _i, _p, _i, _i, _p, _i, _p, _l, _i, _p, _i, _p],
+    "hrseg_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p],
+    "hrseg_maxpool2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "hrseg_maxpool2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "hrseg_bilinear_fwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hrseg_bilinear_bwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hrseg_add": [_p, _i, _p, _i, _p, _i, _i, _l, _i, _p],
+    "hrseg_copy": [_p, _i, _p, _i, _i, _l, _i, _p],
+    "hrseg_relu_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _p],
+    "hrseg_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hrseg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
+    "hrseg_gap_nchw": [_p, _p, _p, _i, _l, _p],
+    "hrseg_film_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "hrseg_film_linear_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "hrseg_head_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    "hrseg_head_bwd": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _i, _l, _i, _i, _p],
+    "hrseg_logits_up_fwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p],
+    "hrseg_logits_up_bwd": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
+    "hrseg_sigmoid_fwd": [_p, _p, _l, _p],
+    "hrseg_sigmoid_bwd": [_p, _l, _l, _l, _p, _p, _i, _i, _i, _l, _p],
+    "hrseg_compose_fwd": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_compose_bwd": [_p, _l, _l, _l, _p, _p, _p, _i, _p, _i, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_loss_partials": [_p, _p, _p, _i, _i, _l, _p],
+    "hrseg_loss_finalize": [_p, _p, _i, _i, _p, _p, _p],
+    "hrseg_loss_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _p],
+    "hrseg_consistency": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_predict_metrics": [_p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    "hrseg_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p],
+    "hrseg_fill": [_p, _f, _l, _p],
+}
+
+_lib.hrseg_last_error_string.restype = C.c_char_p
+_lib.hrseg_last_error_string.argtypes = []
+_lib.hrseg_abi_version.restype = _i
+_lib.hrseg_abi_version.argtypes = []
+
+_fn = {}
+for _name, _args in PROTOTYPES.items():
+    f = getattr(_lib, _name)       # AttributeError here = header and library disagree
+    f.argtypes = _args
+    f.restype = _i
+    _fn[_name] = f
+
+
+def abi_version() -> int:
+    return int(_lib.hrseg_abi_version())
+
+
+def last_error() -> str:
+    return (_lib.hrseg_last_error_string() or b"").decode()
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current stream; raise on failure."""
+    rc = _fn[name](*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def int_array(values):
+    return (C.c_int * len(values))(*values)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("hrseg_amd: no GPU visible; the product path runs on MI355X only "
+                           "(the CPU oracle under oracle/ is test infrastructure, not a fallback)")

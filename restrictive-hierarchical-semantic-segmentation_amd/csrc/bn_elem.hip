@@ -1,0 +1,681 @@
+// Batch-norm (training statistics, apply, backward), pooling, bilinear resize and
+// elementwise glue on NHWC fp32 for gfx950.  All HBM-bound: one pass per tensor,
+// 16-byte accesses, per-channel parameters held in registers.
+//
+// Thread mapping used throughout ("pixel lanes x channel quads"): with
+// Q = C/4 channel quads, thread t owns quad t % Q for pixel lane t / Q
+// (P = 256/Q lanes per block; threads beyond P*Q idle).  Consecutive threads
+// read consecutive 16-byte pieces of a pixel row, so a wave covers whole rows.
+#include "common.h"
+
+struct Lanes {
+  int Q, P, cq, pl;
+  bool active;
+};
+__device__ __forceinline__ Lanes make_lanes(int C) {
+  Lanes l;
+  l.Q = C >> 2;
+  l.P = (l.Q >= 256) ? 1 : 256 / l.Q;
+  l.cq = threadIdx.x % l.Q;
+  l.pl = threadIdx.x / l.Q;
+  l.active = l.pl < l.P;
+  return l;
+}
+static int elem_grid(long npix, int C) {
+  const int Q = C / 4, P = (Q >= 256) ? 1 : 256 / Q;
+  long blocks = (npix + P - 1) / P;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+#define FOR_PIXELS(pix, L, npix) \
+  for (long pix = (long)blockIdx.x * (L).P + (L).pl; pix < (npix); pix += (long)gridDim.x * (L).P)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// C > 1024 is not supported by the quad mapping (Q must be <= 256): the widest
+// tensor on the path is the UNet 1024-channel concat.
+static int check_c(int C, const char* who) {
+  HRSEG_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1024, "%s: C=%d must be a multiple of 4 and <= 1024", who, C);
+  return 0;
+}
+
+// --------------------------------------------------------------------------- BN statistics
+// partial[chunk][0][c] = sum y, partial[chunk][1][c] = sum y*y over the chunk's pixels
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, int ldy, long npix, int C,
+                                                       double* __restrict__ partial, long pix_per_chunk) {
+  __shared__ double red[256 * 8];
+  const Lanes L = make_lanes(C);
+  const long lo = (long)blockIdx.x * pix_per_chunk;
+  const long hi = (lo + pix_per_chunk < npix) ? lo + pix_per_chunk : npix;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+  if (L.active)
+    for (long pix = lo + L.pl; pix < hi; pix += L.P) {
+      const f32x4 v = ld4(y + pix * ldy + 4 * L.cq);
+      s += v;
+      ss += v * v;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = s[j];
+    red[threadIdx.x * 8 + 4 + j] = ss[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int pl = 0; pl < L.P; ++pl) {
+      const int t = pl * L.Q + (c >> 2);
+      a += red[t * 8 + (c & 3)];
+      b += red[t * 8 + 4 + (c & 3)];
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// coef: [0]=mean [1]=rstd [2]=scale [3]=shift
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchunks, long npix, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
+                                   float momentum, float eps, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    s += partial[((size_t)k * 2 + 0) * C + c];
+    ss += partial[((size_t)k * 2 + 1) * C + c];
+  }
+  const double mean = s / (double)npix;
+  double var = ss / (double)npix - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  coef[c] = (float)mean;
+  coef[C + c] = rstd;
+  coef[2 * C + c] = g * rstd;
+  coef[3 * C + c] = b - (float)mean * g * rstd;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar) {
+    const double unb = (npix > 1) ? var * (double)npix / (double)(npix - 1) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                    float eps, int C, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  coef[c] = rmean[c];
+  coef[C + c] = rstd;
+  coef[2 * C + c] = g * rstd;
+  coef[3 * C + c] = b - rmean[c] * g * rstd;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy,
+                                                       const float* __restrict__ coef,
+                                                       const float* __restrict__ res, int ldr, int relu,
+                                                       float* __restrict__ z, int ldz, long npix, int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const f32x4 sc = ld4(coef + 2 * C + 4 * L.cq), sh = ld4(coef + 3 * C + 4 * L.cq);
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 v = ld4(y + pix * ldy + 4 * L.cq) * sc + sh;
+    if (res) v += ld4(res + pix * ldr + 4 * L.cq);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st4(z + pix * ldz + 4 * L.cq, v);
+  }
+}
+
+// partial[chunk][0][c] = sum g, [1][c] = sum g*xhat, with g = dz * (z > 0 if relu)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
+                                                            const float* __restrict__ z, int ldz, int relu,
+                                                            const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ coef, long npix, int C,
+                                                            double* __restrict__ partial, long pix_per_chunk) {
+  __shared__ double red[256 * 8];
+  const Lanes L = make_lanes(C);
+  const long lo = (long)blockIdx.x * pix_per_chunk;
+  const long hi = (lo + pix_per_chunk < npix) ? lo + pix_per_chunk : npix;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+  if (L.active) {
+    const f32x4 mean = ld4(coef + 4 * L.cq), rstd = ld4(coef + C + 4 * L.cq);
+    for (long pix = lo + L.pl; pix < hi; pix += L.P) {
+      f32x4 g = ld4(dz + pix * lddz + 4 * L.cq);
+      if (relu) {
+        const f32x4 zz = ld4(z + pix * ldz + 4 * L.cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
+      }
+      const f32x4 xh = (ld4(y + pix * ldy + 4 * L.cq) - mean) * rstd;
+      s += g;
+      sx += g * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = s[j];
+    red[threadIdx.x * 8 + 4 + j] = sx[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int pl = 0; pl < L.P; ++pl) {
+      const int t = pl * L.Q + (c >> 2);
+      a += red[t * 8 + (c & 3)];
+      b += red[t * 8 + 4 + (c & 3)];
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// totals into partial[0][0..1][c] (in place), dgamma/dbeta accumulation
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ partial, int nchunks, int C, float* dgamma,
+                                       float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    s += partial[((size_t)k * 2 + 0) * C + c];
+    sx += partial[((size_t)k * 2 + 1) * C + c];
+  }
+  partial[c] = s;
+  partial[C + c] = sx;
+  if (dgamma) dgamma[c] += (float)sx;
+  if (dbeta) dbeta[c] += (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const double* __restrict__ totals,
+                                                           const float* __restrict__ dz, int lddz,
+                                                           const float* __restrict__ z, int ldz, int relu,
+                                                           const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ coef,
+                                                           float* __restrict__ dy, int lddy,
+                                                           float* __restrict__ dres, int lddres, int dres_acc,
+                                                           long npix, int C, int eval_mode) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const f32x4 mean = ld4(coef + 4 * L.cq), rstd = ld4(coef + C + 4 * L.cq), scale = ld4(coef + 2 * C + 4 * L.cq);
+  f32x4 mg, mgx;
+  const float inv = eval_mode ? 0.f : (float)(1.0 / (double)npix);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mg[j] = (float)(totals[4 * L.cq + j]) * inv;
+    mgx[j] = (float)(totals[C + 4 * L.cq + j]) * inv;
+  }
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 g = ld4(dz + pix * lddz + 4 * L.cq);
+    if (relu) {
+      const f32x4 zz = ld4(z + pix * ldz + 4 * L.cq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
+    }
+    const f32x4 xh = (ld4(y + pix * ldy + 4 * L.cq) - mean) * rstd;
+    st4(dy + pix * lddy + 4 * L.cq, scale * (g - mg - xh * mgx));
+    if (dres) {
+      float* d = dres + pix * lddres + 4 * L.cq;
+      st4(d, dres_acc ? ld4(d) + g : g);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- max pool 2x2 (floor)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ y, int ldy, int B, int Hi, int Wi,
+                                                           int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const int Ho = Hi / 2, Wo = Wi / 2;
+  const long npix = (long)B * Ho * Wo;
+  FOR_PIXELS(pix, L, npix) {
+    const int b = (int)(pix / ((long)Ho * Wo));
+    const int rem = (int)(pix - (long)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* p = x + (((size_t)b * Hi + 2 * oy) * Wi + 2 * ox) * ldx + 4 * L.cq;
+    f32x4 m = ld4(p);
+    const f32x4 v1 = ld4(p + ldx), v2 = ld4(p + (size_t)Wi * ldx), v3 = ld4(p + (size_t)Wi * ldx + ldx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
+    st4(y + pix * ldy + 4 * L.cq, m);
+  }
+}
+
+// gradient goes to the first maximum in scan order (strict >), as torch's max_pool2d
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ dy, int lddy,
+                                                           float* __restrict__ dx, int lddx, int acc, int B,
+                                                           int Hi, int Wi, int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const int Hc = (Hi + 1) / 2, Wc = (Wi + 1) / 2;  // cells incl. the odd leftover row/col
+  const int Ho = Hi / 2, Wo = Wi / 2;
+  const long ncell = (long)B * Hc * Wc;
+  FOR_PIXELS(cell, L, ncell) {
+    const int b = (int)(cell / ((long)Hc * Wc));
+    const int rem = (int)(cell - (long)b * Hc * Wc);
+    const int oy = rem / Wc, ox = rem - oy * Wc;
+    const size_t base = (((size_t)b * Hi + 2 * oy) * Wi + 2 * ox);
+    const bool full = (oy < Ho) & (ox < Wo);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    int arg[4] = {-1, -1, -1, -1};
+    if (full) {
+      g = ld4(dy + (((size_t)b * Ho + oy) * Wo + ox) * lddy + 4 * L.cq);
+      f32x4 m = ld4(x + base * ldx + 4 * L.cq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) arg[j] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const f32x4 v = ld4(x + (base + (k >> 1) * Wi + (k & 1)) * ldx + 4 * L.cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > m[j]) { m[j] = v[j]; arg[j] = k; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+      if (iy >= Hi || ix >= Wi) continue;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (arg[j] == k) ? g[j] : 0.f;
+      float* d = dx + (base + (k >> 1) * Wi + (k & 1)) * lddx + 4 * L.cq;
+      st4(d, acc ? ld4(d) + o : o);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- bilinear
+// source coordinate exactly as torch's upsample_bilinear2d (fp32 arithmetic)
+__device__ __forceinline__ void src_index(int o, float scale, int in_size, int align, int& i0, int& i1,
+                                          float& l0, float& l1) {
+  float r;
+  if (align) {
+    r = scale * (float)o;
+  } else {
+    r = scale * ((float)o + 0.5f) - 0.5f;
+    if (r < 0.f) r = 0.f;
+  }
+  i0 = (int)r;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = r - (float)i0;
+  l0 = 1.f - l1;
+}
+static float resize_scale(int in_size, int out_size, int align) {
+  if (align) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  return (float)in_size / (float)out_size;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ in, int ldin, int B, int Hi,
+                                                           int Wi, int C, float* __restrict__ out, int ldout,
+                                                           int Hout, int Wout, int Hr, int Wr, int py, int px,
+                                                           float sh, float sw, int align, int acc, int relu) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const long npix = (long)B * Hout * Wout;
+  FOR_PIXELS(pix, L, npix) {
+    const int b = (int)(pix / ((long)Hout * Wout));
+    const int rem = (int)(pix - (long)b * Hout * Wout);
+    const int oy = rem / Wout - py, ox = rem % Wout - px;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (oy >= 0 && oy < Hr && ox >= 0 && ox < Wr) {
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      src_index(oy, sh, Hi, align, y0, y1, ly0, ly1);
+      src_index(ox, sw, Wi, align, x0, x1, lx0, lx1);
+      const float* p = in + (size_t)b * Hi * Wi * ldin + 4 * L.cq;
+      const f32x4 v00 = ld4(p + ((size_t)y0 * Wi + x0) * ldin), v01 = ld4(p + ((size_t)y0 * Wi + x1) * ldin);
+      const f32x4 v10 = ld4(p + ((size_t)y1 * Wi + x0) * ldin), v11 = ld4(p + ((size_t)y1 * Wi + x1) * ldin);
+      v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    }
+    float* o = out + pix * ldout + 4 * L.cq;
+    if (acc) v += ld4(o);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st4(o, v);
+  }
+}
+
+// gather form of the transpose: every input pixel sums the output pixels that read it
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dout, int lddout, int B,
+                                                           int Hi, int Wi, int C, float* __restrict__ din,
+                                                           int lddin, int Hout, int Wout, int Hr, int Wr, int py,
+                                                           int px, float sh, float sw, int align, int acc) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const long npix = (long)B * Hi * Wi;
+  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+  FOR_PIXELS(pix, L, npix) {
+    const int b = (int)(pix / ((long)Hi * Wi));
+    const int rem = (int)(pix - (long)b * Hi * Wi);
+    const int iy = rem / Wi, ix = rem - iy * Wi;
+    // candidate output rows/cols: src in (iy-1, iy+1)  (whole range when scale is 0)
+    int oy_lo = 0, oy_hi = Hr - 1, ox_lo = 0, ox_hi = Wr - 1;
+    if (sh > 0.f) {
+      oy_lo = max(0, (int)floorf(((float)iy - 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) - 1);
+      oy_hi = min(Hr - 1, (int)ceilf(((float)iy + 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) + 1);
+    }
+    if (sw > 0.f) {
+      ox_lo = max(0, (int)floorf(((float)ix - 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) - 1);
+      ox_hi = min(Wr - 1, (int)ceilf(((float)ix + 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) + 1);
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      src_index(oy, sh, Hi, align, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      const float* row = dout + (((size_t)b * Hout + oy + py) * Wout + px) * lddout + 4 * L.cq;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        src_index(ox, sw, Wi, align, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        s += (wy * wx) * ld4(row + (size_t)ox * lddout);
+      }
+    }
+    float* d = din + pix * lddin + 4 * L.cq;
+    st4(d, acc ? ld4(d) + s : s);
+  }
+}
+
+// --------------------------------------------------------------------------- small glue
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                  int ldb, float* __restrict__ out, int ldo, int relu, long npix,
+                                                  int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 v = ld4(a + pix * lda + 4 * L.cq) + ld4(b + pix * ldb + 4 * L.cq);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st4(out + pix * ldo + 4 * L.cq, v);
+  }
+}
+__global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out,
+                                                   int ldout, int acc, long npix, int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 v = ld4(in + pix * ldin + 4 * L.cq);
+    float* o = out + pix * ldout + 4 * L.cq;
+    st4(o, acc ? ld4(o) + v : v);
+  }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dz, int lddz,
+                                                       const float* __restrict__ z, int ldz, float* __restrict__ dx,
+                                                       int lddx, long npix, int C) {
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 g = ld4(dz + pix * lddz + 4 * L.cq);
+    const f32x4 zz = ld4(z + pix * ldz + 4 * L.cq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
+    st4(dx + pix * lddx + 4 * L.cq, g);
+  }
+}
+
+// NCHW <-> NHWC for narrow tensors (image: C=3, logits: C<=16): thread per pixel
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int ldout, int B, int C,
+                                    long hw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * hw) return;
+  const long b = i / hw, p = i - b * hw;
+  for (int c = 0; c < C; ++c) out[i * ldout + c] = in[(b * C + c) * hw + p];
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out, int B, int C,
+                                    long hw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * hw) return;
+  const long b = i / hw, p = i - b * hw;
+  for (int c = 0; c < C; ++c) out[(b * C + c) * hw + p] = in[i * ldin + c];
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// AdamW over one flat buffer (torch.optim.AdamW single-tensor semantics)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n4, long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float rsqrt_bc2, float gscale) {
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = ld4(p + 4 * i), gg = ld4(g + 4 * i) * gscale, mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+    pp = pp * (1.f - lr * wd);
+    mm = mm + (gg - mm) * (1.f - b1);          // lerp, as torch: m.lerp_(g, 1-b1)
+    vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pp[j] -= step * mm[j] / (sqrtf(vv[j]) * rsqrt_bc2 + eps);
+    st4(p + 4 * i, pp);
+    st4(m + 4 * i, mm);
+    st4(v + 4 * i, vv);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) {  // tail
+    const long i = 4 * n4 + threadIdx.x;
+    float pp = p[i] * (1.f - lr * wd), gg = g[i] * gscale;
+    const float mm = m[i] + (gg - m[i]) * (1.f - b1), vv = v[i] * b2 + gg * gg * (1.f - b2);
+    p[i] = pp - step * mm / (sqrtf(vv) * rsqrt_bc2 + eps);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+// =========================================================================== C ABI
+static long chunk_size(long npix, int nchunks) { return (npix + nchunks - 1) / nchunks; }
+
+extern "C" int hrseg_bn_stats(const float* y, int ldy, long npix, int C, double* partial, int nchunks,
+                              hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bn_stats")) return e;
+  HRSEG_CHECK_ARG(y && partial && npix > 0 && nchunks > 0 && ldy >= C, "hrseg_bn_stats: bad arguments");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, y, ldy, npix, C, partial,
+                     chunk_size(npix, nchunks));
+  HRSEG_LAUNCH_CHECK("bn_stats");
+  return 0;
+}
+
+extern "C" int hrseg_bn_finalize(const double* partial, int nchunks, long npix, int C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float momentum, float eps, float* coef,
+                                 hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(partial && coef && C > 0 && nchunks > 0 && npix > 0, "hrseg_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nchunks,
+                     npix, C, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+                     coef);
+  HRSEG_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
+extern "C" int hrseg_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* coef, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(running_mean && running_var && coef && C > 0, "hrseg_bn_eval_coef: bad arguments");
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, coef);
+  HRSEG_LAUNCH_CHECK("bn_eval_coef");
+  return 0;
+}
+
+extern "C" int hrseg_bn_apply(const float* y, int ldy, const float* coef, const float* residual, int ldr, int relu,
+                              float* z, int ldz, long npix, int C, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bn_apply")) return e;
+  HRSEG_CHECK_ARG(y && coef && z && npix > 0 && ldy >= C && ldz >= C && (ldy % 4 == 0) && (ldz % 4 == 0),
+                  "hrseg_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
+                     residual, ldr, relu, z, ldz, npix, C);
+  HRSEG_LAUNCH_CHECK("bn_apply");
+  return 0;
+}
+
+extern "C" int hrseg_bn_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, int relu, const float* y,
+                                   int ldy, const float* coef, long npix, int C, double* partial, int nchunks,
+                                   hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bn_bwd_reduce")) return e;
+  HRSEG_CHECK_ARG(dz && y && coef && partial && (!relu || z) && npix > 0 && nchunks > 0,
+                  "hrseg_bn_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, relu, y,
+                     ldy, coef, npix, C, partial, chunk_size(npix, nchunks));
+  HRSEG_LAUNCH_CHECK("bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int lddz, const float* z,
+                                  int ldz, int relu, const float* y, int ldy, const float* coef, const float* gamma,
+                                  float* dgamma, float* dbeta, float* dy, int lddy, float* dres, int lddres,
+                                  int dres_accumulate, long npix, int C, int eval_mode, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bn_bwd_apply")) return e;
+  (void)gamma;
+  HRSEG_CHECK_ARG(partial && dz && y && coef && dy && (!relu || z) && npix > 0 && nchunks > 0,
+                  "hrseg_bn_bwd_apply: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (double*)partial, nchunks, C,
+                     dgamma, dbeta);
+  HRSEG_LAUNCH_CHECK("bn_bwd_finalize");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, st, partial, dz, lddz, z, ldz, relu,
+                     y, ldy, coef, dy, lddy, dres, lddres, dres_accumulate, npix, C, eval_mode);
+  HRSEG_LAUNCH_CHECK("bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int hrseg_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int B, int Hi, int Wi, int C,
+                                  hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_maxpool2_fwd")) return e;
+  HRSEG_CHECK_ARG(x && y && B > 0 && Hi >= 2 && Wi >= 2, "hrseg_maxpool2_fwd: bad arguments");
+  const long npix = (long)B * (Hi / 2) * (Wi / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                     B, Hi, Wi, C);
+  HRSEG_LAUNCH_CHECK("maxpool2_fwd");
+  return 0;
+}
+
+extern "C" int hrseg_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
+                                  int accumulate, int B, int Hi, int Wi, int C, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_maxpool2_bwd")) return e;
+  HRSEG_CHECK_ARG(x && dy && dx && B > 0 && Hi >= 2 && Wi >= 2, "hrseg_maxpool2_bwd: bad arguments");
+  const long ncell = (long)B * ((Hi + 1) / 2) * ((Wi + 1) / 2);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(elem_grid(ncell, C)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy,
+                     lddy, dx, lddx, accumulate, B, Hi, Wi, C);
+  HRSEG_LAUNCH_CHECK("maxpool2_bwd");
+  return 0;
+}
+
+extern "C" int hrseg_bilinear_fwd(const float* in, int ldin, int B, int Hi, int Wi, int C, float* out, int ldout,
+                                  int Hout, int Wout, int Hr, int Wr, int py, int px, int align_corners,
+                                  int accumulate, int relu, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bilinear_fwd")) return e;
+  HRSEG_CHECK_ARG(in && out && B > 0 && Hi > 0 && Wi > 0 && Hr > 0 && Wr > 0 && py >= 0 && px >= 0 &&
+                      py + Hr <= Hout && px + Wr <= Wout,
+                  "hrseg_bilinear_fwd: placed image %dx%d at (%d,%d) does not fit %dx%d", Hr, Wr, py, px, Hout, Wout);
+  const long npix = (long)B * Hout * Wout;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, in, ldin, B, Hi,
+                     Wi, C, out, ldout, Hout, Wout, Hr, Wr, py, px, resize_scale(Hi, Hr, align_corners),
+                     resize_scale(Wi, Wr, align_corners), align_corners, accumulate, relu);
+  HRSEG_LAUNCH_CHECK("bilinear_fwd");
+  return 0;
+}
+
+extern "C" int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, int Wi, int C, float* din, int lddin,
+                                  int Hout, int Wout, int Hr, int Wr, int py, int px, int align_corners,
+                                  int accumulate, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_bilinear_bwd")) return e;
+  HRSEG_CHECK_ARG(dout && din && B > 0 && Hi > 0 && Wi > 0 && Hr > 0 && Wr > 0 && py >= 0 && px >= 0 &&
+                      py + Hr <= Hout && px + Wr <= Wout,
+                  "hrseg_bilinear_bwd: bad geometry");
+  const long npix = (long)B * Hi * Wi;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, dout, lddout, B,
+                     Hi, Wi, C, din, lddin, Hout, Wout, Hr, Wr, py, px, resize_scale(Hi, Hr, align_corners),
+                     resize_scale(Wi, Wr, align_corners), align_corners, accumulate);
+  HRSEG_LAUNCH_CHECK("bilinear_bwd");
+  return 0;
+}
+
+extern "C" int hrseg_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int relu, long npix,
+                         int C, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_add")) return e;
+  HRSEG_CHECK_ARG(a && b && out && npix > 0, "hrseg_add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo,
+                     relu, npix, C);
+  HRSEG_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int hrseg_copy(const float* in, int ldin, float* out, int ldout, int accumulate, long npix, int C,
+                          hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_copy")) return e;
+  HRSEG_CHECK_ARG(in && out && npix > 0, "hrseg_copy: bad arguments");
+  hipLaunchKernelGGL(copy_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout,
+                     accumulate, npix, C);
+  HRSEG_LAUNCH_CHECK("copy");
+  return 0;
+}
+
+extern "C" int hrseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz, float* dx, int lddx, long npix,
+                              int C, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_relu_bwd")) return e;
+  HRSEG_CHECK_ARG(dz && z && dx && npix > 0, "hrseg_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+                     dx, lddx, npix, C);
+  HRSEG_LAUNCH_CHECK("relu_bwd");
+  return 0;
+}
+
+extern "C" int hrseg_nchw_to_nhwc(const float* in, float* out, int ldout, int B, int C, int H, int W,
+                                  hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(in && out && B > 0 && C > 0 && ldout >= C, "hrseg_nchw_to_nhwc: bad arguments");
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, ldout, B,
+                     C, (long)H * W);
+  HRSEG_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int hrseg_nhwc_to_nchw(const float* in, int ldin, float* out, int B, int C, int H, int W,
+                                  hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(in && out && B > 0 && C > 0 && ldin >= C, "hrseg_nhwc_to_nchw: bad arguments");
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, in, ldin, out, B,
+                     C, (long)H * W);
+  HRSEG_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+
+extern "C" int hrseg_fill(float* p, float v, long n, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(p && n >= 0, "hrseg_fill: bad arguments");
+  if (n == 0) return 0;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  HRSEG_LAUNCH_CHECK("fill");
+  return 0;
+}
+
+extern "C" int hrseg_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, float bc1, float bc2, float gscale,
+                           hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(p && g && m && v && n > 0, "hrseg_adamw: bad arguments");
+  HRSEG_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                      ((uintptr_t)v % 16 == 0),
+                  "hrseg_adamw: buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, 1.0f / sqrtf(bc2), gscale);
+  HRSEG_LAUNCH_CHECK("adamw");
+  return 0;
+}

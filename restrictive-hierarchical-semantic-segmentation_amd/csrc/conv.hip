@@ -1,0 +1,615 @@
+// Convolution forward / data-gradient / weight-gradient for gfx950 (MI355X).
+//
+// Implicit GEMM on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32
+// (64 lanes: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]).
+// Replaces nn.Conv2d of the reference (Models/models.py:113,116,322-324,
+// 364-370,483-511,579-582,614,656,690,701) and its autograd backward.
+//
+//  * forward / dgrad: one kernel (igemm_conv).  GEMM rows are output pixels
+//    gathered on the fly (im2col by address generation, nothing materialised
+//    in HBM), columns are output channels; K runs over taps x 16-channel
+//    chunks.  A = weights (M = channels), B = pixels (N), so a lane ends up
+//    with 4 consecutive channels of one pixel -> one 16-byte NHWC store.
+//    dgrad is the same kernel on dy with the transposed weights and a tap
+//    table; stride-2 dgrad runs as 4 output-parity classes with 1/2/2/4 taps.
+//  * wgrad: dW[co][t][ci] = sum_pix dy[pix][co] * x[pix_t][ci]; each block owns
+//    one (tap, cout tile, cin tile) and a pixel range, its 4 waves split the
+//    pixels, reduce through LDS and add into dW with fp32 atomics (dW holds
+//    the running gradient of the step, so the add IS the accumulation).
+//  * Cin <= 4 (the image layer): direct VALU kernels.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+struct IgemmArgs {
+  const float* x;     // input pixels  [B,Hi,Wi,K]  row stride ldx
+  const float* w;     // weights [N][T][K]
+  const float* bias;  // [N] or null
+  float* y;           // output [B,Hy,Wy,N] row stride ldy
+  int ldx, ldy;
+  int B, Hi, Wi, K;          // K = input channels of this GEMM
+  int Ho, Wo, N;             // iteration grid (GEMM rows = B*Ho*Wo), N = output channels
+  int M;                     // B*Ho*Wo
+  int sy, sx;                // input coord = o*s + off[t]
+  int Hy, Wy, oys, oxs, oy0, ox0;  // output pixel = (oy*oys+oy0, ox*oxs+ox0) in Hy x Wy
+  int ntaps;
+  unsigned long long offy_pk, offx_pk, wtap_pk;  // 4 bits per tap: off+8, off+8, weight tap
+  int T;                     // taps stored per weight row (1 or 9)
+  int accumulate;            // y += result
+};
+
+// swizzle of the 16-byte slot inside a 64-byte LDS row so that every 16-lane
+// group of a ds_read_b128 fragment read hits 16 distinct slots of the bank row
+__device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ ((-(row >> 2)) & 3); }
+
+template <int WTM, int WTN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
+  constexpr int BM = 64 * WTM;  // pixels per block (4 waves x WTM tiles x 16)
+  constexpr int BN = 16 * WTN;  // channels per block
+  constexpr int A_LOADS = BM / 64;
+  constexpr int B_LOADS = (BN * 4 + 255) / 256;
+  constexpr int STAGE = (BM + BN) * 16;  // floats per LDS buffer
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = p.N / BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+
+  // rows this thread stages: r = (tid>>2) + 64*i, 16-byte slot q = tid&3
+  const int q = tid & 3;
+  int rpix[A_LOADS], riy[A_LOADS], rix[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    if (m < p.M) {
+      const int b = m / (p.Ho * p.Wo);
+      const int rem = m - b * (p.Ho * p.Wo);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      rpix[i] = b * p.Hi * p.Wi;
+      riy[i] = oy * p.sy;
+      rix[i] = ox * p.sx;
+    } else {
+      rpix[i] = 0;
+      riy[i] = -(1 << 20);
+      rix[i] = 0;
+    }
+  }
+  const int kchunks = p.K >> 4;
+  const int nstages = p.ntaps * kchunks;
+
+  f32x4 ra[A_LOADS], rb[B_LOADS];
+  auto stage_load = [&](int s) {
+    const int t = s / kchunks, c0 = (s - t * kchunks) << 4;
+    const int oy = (int)((p.offy_pk >> (4 * t)) & 15) - 8;
+    const int ox = (int)((p.offx_pk >> (4 * t)) & 15) - 8;
+    const int wt = (int)((p.wtap_pk >> (4 * t)) & 15);
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int iy = riy[i] + oy, ix = rix[i] + ox;
+      const bool ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t off = (size_t)(rpix[i] + iy * p.Wi + ix) * p.ldx + c0 + 4 * q;
+        v = *reinterpret_cast<const f32x4*>(p.x + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int f = tid + 256 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (f < BN * 4) {
+        const size_t off = ((size_t)(n0 + (f >> 2)) * p.T + wt) * p.K + c0 + 4 * (f & 3);
+        v = *reinterpret_cast<const f32x4*>(p.w + off);
+      }
+      rb[i] = v;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    float* base = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int r = (tid >> 2) + 64 * i;
+      *reinterpret_cast<f32x4*>(base + r * 16 + 4 * lds_slot(r, q)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int f = tid + 256 * i;
+      if (f < BN * 4) {
+        const int r = f >> 2;
+        *reinterpret_cast<f32x4*>(base + BM * 16 + r * 16 + 4 * lds_slot(r, f & 3)) = rb[i];
+      }
+    }
+  };
+
+  f32x4 acc[WTN][WTM];
+#pragma unroll
+  for (int n = 0; n < WTN; ++n)
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offset of this lane inside a 16-row tile
+  const int frow = lane & 15;
+  const int foff = frow * 16 + 4 * lds_slot(frow, lane >> 4);
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) stage_load(s + 1);
+    const float* base = lds + (s & 1) * STAGE;
+    f32x4 xf[WTM], wf[WTN];
+#pragma unroll
+    for (int m = 0; m < WTM; ++m)
+      xf[m] = *reinterpret_cast<const f32x4*>(base + (wave * 16 * WTM + 16 * m) * 16 + foff);
+#pragma unroll
+    for (int n = 0; n < WTN; ++n)
+      wf[n] = *reinterpret_cast<const f32x4*>(base + BM * 16 + (16 * n) * 16 + foff);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int n = 0; n < WTN; ++n)
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
+    if (more) stage_store((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds channels n0+16n+4g..+3 of pixel row (lane&15)
+  const int g = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    const int row = m0 + wave * 16 * WTM + 16 * m + (lane & 15);
+    if (row >= p.M) continue;
+    const int b = row / (p.Ho * p.Wo);
+    const int rem = row - b * (p.Ho * p.Wo);
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const size_t pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
+    float* yrow = p.y + pix * p.ldy;
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      const int ch = n0 + 16 * n + 4 * g;
+      f32x4 v = acc[n][m];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+      *reinterpret_cast<f32x4*>(yrow + ch) = v;
+    }
+  }
+}
+
+// zero-fill of output pixels a stride-2 dgrad never visits is not needed: the
+// four parity classes cover every input pixel (a class with no tap in range
+// still writes zeros because its loads are predicated off).
+
+template <int WTM, int WTN>
+static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
+  constexpr int BM = 64 * WTM, BN = 16 * WTN;
+  const int grid = ceil_div(a.M, BM) * (a.N / BN);
+  hipLaunchKernelGGL((igemm_conv_kernel<WTM, WTN>), dim3(grid), dim3(256), 0, st, a);
+  return 0;
+}
+
+static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
+  // channel tile: 48 for 48-multiples (48,96,192,384,720), 64 for 64-multiples,
+  // else 16/32; pixel tile 256 when that still gives >= 2 blocks per CU.
+  const bool big = ((long)ceil_div(a.M, 256) * (a.N / ((a.N % 48 == 0) ? 48 : (a.N % 64 == 0) ? 64 : 16))) >= 512;
+  if (a.N % 48 == 0) return big ? launch_igemm<4, 3>(a, st) : launch_igemm<2, 3>(a, st);
+  if (a.N % 64 == 0) return big ? launch_igemm<4, 4>(a, st) : launch_igemm<2, 4>(a, st);
+  if (a.N % 32 == 0) return launch_igemm<2, 2>(a, st);
+  return launch_igemm<2, 1>(a, st);
+}
+
+// --------------------------------------------------------------------------- direct conv, Cin <= 4
+// y[b,oy,ox,co] = bias[co] + sum_{t,ci} x[b, oy*s+kh-1, ox*s+kw-1, ci] * w[co][t][ci]
+// one thread = one output pixel x 16 channels; weights of the block's 64 channels in LDS.
+__global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int ldy, int B, int Hi,
+                                                                 int Wi, int Cin, int Ho, int Wo, int Cout,
+                                                                 int ks, int stride) {
+  __shared__ float wl[64 * 9 * 4];
+  const int T = ks * ks, pad = (ks - 1) / 2;
+  const int cb = blockIdx.y * 64;  // channel block
+  for (int i = threadIdx.x; i < 64 * T * Cin; i += 256) {
+    const int co = i / (T * Cin);
+    wl[i] = (cb + co < Cout) ? w[(size_t)(cb + co) * T * Cin + (i - co * T * Cin)] : 0.f;
+  }
+  __syncthreads();
+  const long M = (long)B * Ho * Wo;
+  const long m = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cg = threadIdx.x >> 6;  // 16-channel group
+  if (m >= M) return;
+  const int b = (int)(m / ((long)Ho * Wo));
+  const int rem = (int)(m - (long)b * Ho * Wo);
+  const int oy = rem / Wo, ox = rem - oy * Wo;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
+    if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+    const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float xv = xp[ci];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(xv, wl[((cg * 16 + j) * T + t) * Cin + ci], acc[j]);
+    }
+  }
+  float* yp = y + (size_t)m * ldy + cb + cg * 16;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int co = cb + cg * 16 + j;
+    if (co < Cout) yp[j] = acc[j] + (bias ? bias[co] : 0.f);
+  }
+}
+
+// dw[co][t][ci] += sum_pix dy[pix][co] * x[pix_t][ci]; thread = (co, tap group), block = pixel range
+__global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* __restrict__ x, int ldx,
+                                                                   const float* __restrict__ dy, int lddy,
+                                                                   float* __restrict__ dw, int B, int Hi,
+                                                                   int Wi, int Cin, int Ho, int Wo, int Cout,
+                                                                   int ks, int stride, int pix_per_block) {
+  const int T = ks * ks, pad = (ks - 1) / 2;
+  const int co = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int tg = threadIdx.x >> 6;  // taps tg, tg+4, tg+8
+  const long M = (long)B * Ho * Wo;
+  const long lo = (long)blockIdx.x * pix_per_block;
+  const long hi = (lo + pix_per_block < M) ? lo + pix_per_block : M;
+  float acc[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+  for (long m = lo; m < hi; ++m) {
+    const int b = (int)(m / ((long)Ho * Wo));
+    const int rem = (int)(m - (long)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float g = (co < Cout) ? dy[(size_t)m * lddy + co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int t = tg + 4 * a;
+      if (t >= T) continue;
+      const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
+      if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+      const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
+      for (int c = 0; c < Cin; ++c) acc[a][c] = fmaf(g, xp[c], acc[a][c]);
+    }
+  }
+  if (co >= Cout) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int t = tg + 4 * a;
+    if (t >= T) continue;
+    for (int c = 0; c < Cin; ++c) atomicAdd(dw + ((size_t)co * T + t) * Cin + c, acc[a][c]);
+  }
+}
+
+// --------------------------------------------------------------------------- wgrad on MFMA
+struct WgradArgs {
+  const float* x;   // [B,Hi,Wi,Cin] ldx
+  const float* dy;  // [B,Ho,Wo,Cout] lddy
+  float* dw;        // [Cout][T][Cin]
+  int ldx, lddy;
+  int B, Hi, Wi, Cin, Ho, Wo, Cout;
+  int M;            // B*Ho*Wo
+  int ks, stride, T;
+  int pix_per_block;  // multiple of 64
+  unsigned long long div_hw, div_w;  // ceil(2^40/(Ho*Wo)), ceil(2^40/Wo)
+};
+
+__device__ __forceinline__ int fast_div(int n, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)n * magic) >> 40);
+}
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);  // row strides with (stride % 32) == 16
+  constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
+  constexpr int STAGE = 64 * (SA + SB);
+  constexpr int RED = 4 * TN * TK * 256;
+  constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // blockIdx.y -> (tap, cout tile, cin tile)
+  const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
+  int id = blockIdx.y;
+  const int kt = id % nkt;
+  id /= nkt;
+  const int ct = id % nct;
+  const int tap = id / nct;
+  const int n0 = ct * 16 * TN, k0 = kt * 16 * TK;
+  const int pad = (p.ks - 1) / 2;
+  const int kh = tap / p.ks - pad, kw = tap % p.ks - pad;
+
+  const int lo = blockIdx.x * p.pix_per_block;
+  const int hi = min(lo + p.pix_per_block, p.M);
+  const int nstages = (hi - lo + 63) >> 6;
+
+  f32x4 ra[TN], rb[TK];
+  auto stage_load = [&](int s) {
+    const int base = lo + (s << 6);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int f = tid + 256 * i;  // float4 index in [64][4*TN]
+      const int r = f / (4 * TN), c4 = f - r * (4 * TN);
+      const int m = base + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + n0 + 4 * c4);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f / (4 * TK), c4 = f - r * (4 * TK);
+      const int m = base + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) {
+        const int b = fast_div(m, p.div_hw);
+        const int rem = m - b * (p.Ho * p.Wo);
+        const int oy = fast_div(rem, p.div_w), ox = rem - oy * p.Wo;
+        const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
+        if ((iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi))
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.ldx + k0 + 4 * c4);
+      }
+      rb[i] = v;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    float* a = lds + buf * STAGE;
+    float* b = a + 64 * SA;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f / (4 * TN), c4 = f - r * (4 * TN);
+      *reinterpret_cast<f32x4*>(a + r * SA + 4 * c4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f / (4 * TK), c4 = f - r * (4 * TK);
+      *reinterpret_cast<f32x4*>(b + r * SB + 4 * c4) = rb[i];
+    }
+  };
+
+  f32x4 acc[TN][TK];
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k) acc[n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nstages > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) stage_load(s + 1);
+    const float* a = lds + (s & 1) * STAGE;
+    const float* b = a + 64 * SA;
+#pragma unroll
+    for (int ks4 = 0; ks4 < 4; ++ks4) {
+      const int row = wave * 16 + ks4 * 4 + (lane >> 4);
+      float af[TN], bf[TK];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) af[n] = a[row * SA + 16 * n + (lane & 15)];
+#pragma unroll
+      for (int k = 0; k < TK; ++k) bf[k] = b[row * SB + 16 * k + (lane & 15)];
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int k = 0; k < TK; ++k)
+          acc[n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n], bf[k], acc[n][k], 0, 0, 0);
+    }
+    if (more) stage_store((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // cross-wave reduction: red[wave][tile][r*64 + lane]
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[((wave * TN + n) * TK + k) * 256 + r * 64 + lane] = acc[n][k][r];
+  __syncthreads();
+  const int r = tid >> 6, l = tid & 63;
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) v += lds[((wv * TN + n) * TK + k) * 256 + tid];
+      const int co = n0 + 16 * n + 4 * (l >> 4) + r;  // D row = 4*(lane>>4)+reg
+      const int ci = k0 + 16 * k + (l & 15);          // D col = lane&15
+      atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
+    }
+}
+
+template <int TN, int TK>
+static int launch_wgrad(WgradArgs a, hipStream_t st) {
+  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
+  // aim for ~1024 blocks; each block at least 4 stages (256 pixels)
+  int ksplit = 1024 / tiles;
+  if (ksplit < 1) ksplit = 1;
+  int ppb = ceil_div(ceil_div(a.M, ksplit), 64) * 64;
+  if (ppb < 256) ppb = 256;
+  a.pix_per_block = ppb;
+  const int gx = ceil_div(a.M, ppb);
+  hipLaunchKernelGGL((wgrad_kernel<TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
+  return 0;
+}
+
+// --------------------------------------------------------------------------- weight transpose
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int T,
+                                        int Cin) {
+  // wt[ci][t][co] = w[co][t][ci]; tile 32x32 through LDS, one tap per blockIdx.z
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int co = co0 + j, ci = ci0 + threadIdx.x;
+    tile[j][threadIdx.x] = (co < Cout && ci < Cin) ? w[((size_t)co * T + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + threadIdx.x;
+    if (co < Cout && ci < Cin) wt[((size_t)ci * T + t) * Cout + co] = tile[threadIdx.x][j];
+  }
+}
+
+// --------------------------------------------------------------------------- C ABI
+static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
+  HRSEG_CHECK_ARG(s != nullptr, "%s: null shape", who);
+  HRSEG_CHECK_ARG(s->ksize == 1 || s->ksize == 3, "%s: ksize %d not in {1,3}", who, s->ksize);
+  HRSEG_CHECK_ARG(s->stride == 1 || s->stride == 2, "%s: stride %d not in {1,2}", who, s->stride);
+  HRSEG_CHECK_ARG(s->B > 0 && s->Hi > 0 && s->Wi > 0 && s->Cin > 0 && s->Cout > 0, "%s: non-positive dims", who);
+  const int pad = (s->ksize - 1) / 2;
+  const int ho = (s->Hi + 2 * pad - s->ksize) / s->stride + 1, wo = (s->Wi + 2 * pad - s->ksize) / s->stride + 1;
+  HRSEG_CHECK_ARG(ho == s->Ho && wo == s->Wo, "%s: output %dx%d does not match input %dx%d k%d s%d (expect %dx%d)",
+                  who, s->Ho, s->Wo, s->Hi, s->Wi, s->ksize, s->stride, ho, wo);
+  HRSEG_CHECK_ARG(s->ldx >= s->Cin && s->ldy >= s->Cout, "%s: ld smaller than channel count", who);
+  HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 30) && (long)s->B * s->Ho * s->Wo < (1L << 21) * 4,
+                  "%s: tensor too large for 32-bit pixel indexing", who);
+  return 0;
+}
+
+static void pack_taps(IgemmArgs& a, int n, const int* oy, const int* ox, const int* wt) {
+  a.ntaps = n;
+  a.offy_pk = a.offx_pk = a.wtap_pk = 0;
+  for (int t = 0; t < n; ++t) {
+    a.offy_pk |= (unsigned long long)(oy[t] + 8) << (4 * t);
+    a.offx_pk |= (unsigned long long)(ox[t] + 8) << (4 * t);
+    a.wtap_pk |= (unsigned long long)wt[t] << (4 * t);
+  }
+}
+
+extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                              const hrseg_conv_shape_t* s, hrseg_stream_t stream) {
+  if (int e = check_shape(s, "hrseg_conv_fwd")) return e;
+  HRSEG_CHECK_ARG(x && w && y, "hrseg_conv_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  HRSEG_CHECK_ARG(s->Cout % 16 == 0 || s->Cin <= 4, "hrseg_conv_fwd: Cout %d not a multiple of 16", s->Cout);
+  if (s->Cin <= 4) {
+    const long M = (long)s->B * s->Ho * s->Wo;
+    dim3 grid(ceil_div(M, 64), ceil_div(s->Cout, 64));
+    hipLaunchKernelGGL(conv_small_cin_fwd_kernel, grid, dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B, s->Hi,
+                       s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride);
+    HRSEG_LAUNCH_CHECK("conv_small_cin_fwd");
+    return 0;
+  }
+  HRSEG_CHECK_ARG(s->Cin % 16 == 0, "hrseg_conv_fwd: Cin %d not a multiple of 16", s->Cin);
+  HRSEG_CHECK_ARG(s->ldx % 4 == 0 && s->ldy % 4 == 0, "hrseg_conv_fwd: ld must be a multiple of 4");
+  IgemmArgs a{};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldx = s->ldx; a.ldy = s->ldy;
+  a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.K = s->Cin;
+  a.Ho = s->Ho; a.Wo = s->Wo; a.N = s->Cout; a.M = s->B * s->Ho * s->Wo;
+  a.sy = a.sx = s->stride;
+  a.Hy = s->Ho; a.Wy = s->Wo; a.oys = a.oxs = 1; a.oy0 = a.ox0 = 0;
+  a.T = s->ksize * s->ksize; a.accumulate = 0;
+  int oy[9], ox[9], wt[9];
+  const int pad = (s->ksize - 1) / 2;
+  for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
+  pack_taps(a, a.T, oy, ox, wt);
+  dispatch_igemm(a, st);
+  HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
+  return 0;
+}
+
+extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int accumulate,
+                                const hrseg_conv_shape_t* s, hrseg_stream_t stream) {
+  if (int e = check_shape(s, "hrseg_conv_dgrad")) return e;
+  HRSEG_CHECK_ARG(dy && wt && dx, "hrseg_conv_dgrad: null pointer");
+  HRSEG_CHECK_ARG(s->Cin % 16 == 0 && s->Cout % 16 == 0, "hrseg_conv_dgrad: channels (%d,%d) must be multiples of 16",
+                  s->Cin, s->Cout);
+  HRSEG_CHECK_ARG(s->ldx % 4 == 0 && s->ldy % 4 == 0, "hrseg_conv_dgrad: ld must be a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+  IgemmArgs a{};
+  a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx; a.ldx = s->ldy; a.ldy = s->ldx;
+  a.B = s->B; a.Hi = s->Ho; a.Wi = s->Wo; a.K = s->Cout;  // GEMM input = dy
+  a.N = s->Cin; a.T = s->ksize * s->ksize; a.accumulate = accumulate;
+  a.Hy = s->Hi; a.Wy = s->Wi;
+  const int ks = s->ksize, pad = (ks - 1) / 2;
+  if (s->stride == 1) {
+    a.Ho = s->Hi; a.Wo = s->Wi; a.M = s->B * s->Hi * s->Wi;
+    a.sy = a.sx = 1; a.oys = a.oxs = 1; a.oy0 = a.ox0 = 0;
+    int oy[9], ox[9], wtp[9];
+    for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
+    pack_taps(a, a.T, oy, ox, wtp);
+    dispatch_igemm(a, st);
+    HRSEG_LAUNCH_CHECK("igemm_conv(dgrad)");
+    return 0;
+  }
+  // stride 2: dx[y,x] = sum_{kh,kw : (y+pad-kh) even, (x+pad-kw) even} dy[(y+pad-kh)/2, (x+pad-kw)/2] w[kh,kw]
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int hc = (s->Hi - py + 1) / 2, wc = (s->Wi - px + 1) / 2;  // pixels of this parity class
+      if (hc <= 0 || wc <= 0) continue;
+      int oy[9], ox[9], wtp[9], n = 0;
+      for (int kh = 0; kh < ks; ++kh)
+        for (int kw = 0; kw < ks; ++kw) {
+          if (((py + pad - kh) & 1) || ((px + pad - kw) & 1)) continue;
+          // y = 2*yy+py  ->  dy row = yy + (py+pad-kh)/2 (arithmetic shift handles -1)
+          oy[n] = (py + pad - kh) >> 1;
+          ox[n] = (px + pad - kw) >> 1;
+          wtp[n] = kh * ks + kw;
+          ++n;
+        }
+      IgemmArgs c = a;
+      c.Ho = hc; c.Wo = wc; c.M = s->B * hc * wc;
+      c.sy = c.sx = 1; c.oys = c.oxs = 2; c.oy0 = py; c.ox0 = px;
+      pack_taps(c, n, oy, ox, wtp);
+      dispatch_igemm(c, st);
+      HRSEG_LAUNCH_CHECK("igemm_conv(dgrad s2)");
+    }
+  return 0;
+}
+
+extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s,
+                                hrseg_stream_t stream) {
+  if (int e = check_shape(s, "hrseg_conv_wgrad")) return e;
+  HRSEG_CHECK_ARG(x && dy && dw, "hrseg_conv_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = s->ksize * s->ksize;
+  if (s->Cin <= 4) {
+    const long M = (long)s->B * s->Ho * s->Wo;
+    const int ppb = 512;
+    dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
+    hipLaunchKernelGGL(conv_small_cin_wgrad_kernel, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi,
+                       s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, ppb);
+    HRSEG_LAUNCH_CHECK("conv_small_cin_wgrad");
+    return 0;
+  }
+  HRSEG_CHECK_ARG(s->Cin % 16 == 0 && s->Cout % 16 == 0, "hrseg_conv_wgrad: channels (%d,%d) must be multiples of 16",
+                  s->Cin, s->Cout);
+  HRSEG_CHECK_ARG(s->ldx % 4 == 0 && s->ldy % 4 == 0, "hrseg_conv_wgrad: ld must be a multiple of 4");
+  WgradArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw; a.ldx = s->ldx; a.lddy = s->ldy;
+  a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.Cin = s->Cin; a.Ho = s->Ho; a.Wo = s->Wo; a.Cout = s->Cout;
+  a.M = s->B * s->Ho * s->Wo; a.ks = s->ksize; a.stride = s->stride; a.T = T;
+  const unsigned long long one = 1ULL << 40;
+  a.div_hw = (one + (unsigned long long)(s->Ho * s->Wo) - 1) / (unsigned long long)(s->Ho * s->Wo);
+  a.div_w = (one + (unsigned long long)s->Wo - 1) / (unsigned long long)s->Wo;
+  const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
+  const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
+#define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { launch_wgrad<TN_, TK_>(a, st); }
+  WG(1, 1) WG(1, 2) WG(1, 3) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 3) WG(2, 4)
+  WG(3, 1) WG(3, 2) WG(3, 3) WG(3, 4) WG(4, 1) WG(4, 2) WG(4, 3) WG(4, 4)
+#undef WG
+  HRSEG_LAUNCH_CHECK("wgrad");
+  return 0;
+}
+
+extern "C" int hrseg_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin,
+                                      hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(w && wt && Cout > 0 && taps > 0 && Cin > 0, "hrseg_weight_transpose: bad arguments");
+  dim3 grid(ceil_div(Cin, 32), ceil_div(Cout, 32), taps);
+  hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, w, wt, Cout, taps, Cin);
+  HRSEG_LAUNCH_CHECK("weight_transpose");
+  return 0;
+}

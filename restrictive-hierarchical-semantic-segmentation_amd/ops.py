@@ -1,0 +1,361 @@
+"""Functional layer over the C ABI: torch tensors in, torch tensors out.
+
+Activations are NHWC fp32 tensors ``[B,H,W,C]`` whose last dim is contiguous;
+a channel slice ``t[..., a:b]`` of a wider NHWC tensor is accepted wherever a
+row stride ("ld") exists in the ABI.  Every function launches on torch's
+current stream and never synchronises.  torch is used for allocation only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvShape, call, ptr
+
+
+def _ld(t):
+    assert t.dim() == 4 and (t.stride(3) == 1 or t.shape[3] == 1), "NHWC tensor with contiguous channels expected"
+    B, H, W, Cn = t.shape
+    # strides of size-1 dims are arbitrary: take ld from the first dim that has extent
+    if W > 1:
+        ld = t.stride(2)
+    elif H > 1:
+        ld = t.stride(1)
+    elif B > 1:
+        ld = t.stride(0)
+    else:
+        ld = Cn
+    assert (H == 1 or t.stride(1) == W * ld) and (B == 1 or t.stride(0) == H * W * ld) and ld >= Cn, \
+        "only channel-sliced NHWC views are supported"
+    return ld
+
+
+def _npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def empty_nhwc(B, H, W, Cn, like):
+    return torch.empty((B, H, W, Cn), dtype=torch.float32, device=like.device)
+
+
+def conv_out_size(h, k, s):
+    pad = (k - 1) // 2
+    return (h + 2 * pad - k) // s + 1
+
+
+def _shape(x_shape, ldx, Cout, ldy, k, s):
+    B, Hi, Wi, Cin = x_shape
+    return ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
+                     Cout=Cout, ldy=ldy, ksize=k, stride=s)
+
+
+# ------------------------------------------------------------------ convolution
+def conv_fwd(x, w, bias, k, s, out=None):
+    """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter)."""
+    B, Hi, Wi, Cin = x.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s)
+    call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
+    return out
+
+
+def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False):
+    """wt = weight_transpose(w): [Cin][k*k][Cout]."""
+    B, Hi, Wi, Cin = x_shape
+    if out is None:
+        out = empty_nhwc(B, Hi, Wi, Cin, dy)
+        accumulate = False
+    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s)
+    call("hrseg_conv_dgrad", ptr(dy), ptr(wt), ptr(out), int(accumulate), C.byref(sh))
+    return out
+
+
+def conv_wgrad(x, dy, dw, k, s):
+    """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
+    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s)
+    call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
+
+
+def weight_transpose(w_store, Cout, taps, Cin, out=None):
+    if out is None:
+        out = torch.empty(Cin * taps * Cout, dtype=torch.float32, device=w_store.device)
+    call("hrseg_weight_transpose", ptr(w_store), ptr(out), Cout, taps, Cin)
+    return out
+
+
+# ------------------------------------------------------------------ batch norm
+def _nchunks(npix, Cn):
+    q = Cn // 4
+    p = 1 if q >= 256 else 256 // q
+    return max(1, min(1024, npix // (8 * p)))
+
+
+def bn_train_coef(y, gamma, beta, running_mean, running_var, nbt, momentum, eps):
+    """batch statistics of y -> coef [4][C] (mean, rstd, scale, shift); updates running stats."""
+    Cn, npix = y.shape[3], _npix(y)
+    nch = _nchunks(npix, Cn)
+    part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
+    coef = torch.empty(4 * Cn, dtype=torch.float32, device=y.device)
+    call("hrseg_bn_stats", ptr(y), _ld(y), npix, Cn, ptr(part), nch)
+    call("hrseg_bn_finalize", ptr(part), nch, npix, Cn, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+         ptr(nbt), float(momentum), float(eps), ptr(coef))
+    return coef
+
+
+def bn_eval_coef(gamma, beta, running_mean, running_var, eps):
+    Cn = running_mean.numel()
+    coef = torch.empty(4 * Cn, dtype=torch.float32, device=running_mean.device)
+    call("hrseg_bn_eval_coef", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), Cn, ptr(coef))
+    return coef
+
+
+def bn_apply(y, coef, residual=None, relu=False, out=None):
+    if out is None:
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    call("hrseg_bn_apply", ptr(y), _ld(y), ptr(coef), ptr(residual), _ld(residual) if residual is not None else 0,
+         int(relu), ptr(out), _ld(out), _npix(y), y.shape[3])
+    return out
+
+
+def bn_bwd(dz, z, relu, y, coef, dgamma, dbeta, dres=None, dres_accumulate=False, eval_mode=False, dy_out=None):
+    """-> dy (gradient w.r.t. the conv output); dgamma/dbeta accumulate; dres (+)= g."""
+    Cn, npix = y.shape[3], _npix(y)
+    nch = _nchunks(npix, Cn)
+    part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
+    dy = dy_out if dy_out is not None else torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    zz = z if relu else None
+    call("hrseg_bn_bwd_reduce", ptr(dz), _ld(dz), ptr(zz), _ld(z) if relu else 0, int(relu), ptr(y), _ld(y), ptr(coef),
+         npix, Cn, ptr(part), nch)
+    call("hrseg_bn_bwd_apply", ptr(part), nch, ptr(dz), _ld(dz), ptr(zz), _ld(z) if relu else 0, int(relu), ptr(y),
+         _ld(y), ptr(coef), None, ptr(dgamma), ptr(dbeta), ptr(dy), _ld(dy), ptr(dres),
+         _ld(dres) if dres is not None else 0, int(dres_accumulate), npix, Cn, int(eval_mode))
+    return dy
+
+
+# ------------------------------------------------------------------ pooling / resize / glue
+def maxpool2_fwd(x):
+    B, H, W, Cn = x.shape
+    y = empty_nhwc(B, H // 2, W // 2, Cn, x)
+    call("hrseg_maxpool2_fwd", ptr(x), _ld(x), ptr(y), _ld(y), B, H, W, Cn)
+    return y
+
+
+def maxpool2_bwd(x, dy, dx=None, accumulate=False):
+    B, H, W, Cn = x.shape
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        accumulate = False
+    call("hrseg_maxpool2_bwd", ptr(x), _ld(x), ptr(dy), _ld(dy), ptr(dx), _ld(dx), int(accumulate), B, H, W, Cn)
+    return dx
+
+
+def bilinear_fwd(x, out, Hr, Wr, py=0, px=0, align_corners=True, accumulate=False, relu=False):
+    """resize x to Hr x Wr and place it at (py,px) of `out` (NHWC view, may be a channel slice)."""
+    B, Hi, Wi, Cn = x.shape
+    call("hrseg_bilinear_fwd", ptr(x), _ld(x), B, Hi, Wi, Cn, ptr(out), _ld(out), out.shape[1], out.shape[2], Hr, Wr,
+         py, px, int(align_corners), int(accumulate), int(relu))
+    return out
+
+
+def bilinear_bwd(dout, x_shape, Hr, Wr, py=0, px=0, align_corners=True, din=None, accumulate=False):
+    B, Hi, Wi, Cn = x_shape
+    if din is None:
+        din = empty_nhwc(B, Hi, Wi, Cn, dout)
+        accumulate = False
+    call("hrseg_bilinear_bwd", ptr(dout), _ld(dout), B, Hi, Wi, Cn, ptr(din), _ld(din), dout.shape[1], dout.shape[2],
+         Hr, Wr, py, px, int(align_corners), int(accumulate))
+    return din
+
+
+def add(a, b, relu=False, out=None):
+    if out is None:
+        out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    call("hrseg_add", ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), int(relu), _npix(a), a.shape[3])
+    return out
+
+
+def copy(src, dst, accumulate=False):
+    call("hrseg_copy", ptr(src), _ld(src), ptr(dst), _ld(dst), int(accumulate), _npix(src), src.shape[3])
+    return dst
+
+
+def relu_bwd(dz, z, out=None):
+    if out is None:
+        out = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    call("hrseg_relu_bwd", ptr(dz), _ld(dz), ptr(z), _ld(z), ptr(out), _ld(out), _npix(z), z.shape[3])
+    return out
+
+
+def nchw_to_nhwc(x):
+    B, Cn, H, W = x.shape
+    out = empty_nhwc(B, H, W, Cn, x)
+    call("hrseg_nchw_to_nhwc", ptr(x), ptr(out), Cn, B, Cn, H, W)
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cn = x.shape
+    out = torch.empty((B, Cn, H, W), dtype=torch.float32, device=x.device)
+    call("hrseg_nhwc_to_nchw", ptr(x), _ld(x), ptr(out), B, Cn, H, W)
+    return out
+
+
+def fill(t, v):
+    call("hrseg_fill", ptr(t), float(v), t.numel())
+    return t
+
+
+# ------------------------------------------------------------------ FiLM / head / composition
+def gap_nchw(p):
+    B, Cn, H, W = p.shape
+    cond = torch.empty((B, Cn), dtype=torch.float32, device=p.device)
+    scratch = torch.empty(B * Cn * 64, dtype=torch.float64, device=p.device)
+    call("hrseg_gap_nchw", ptr(p), ptr(cond), ptr(scratch), B * Cn, H * W)
+    return cond
+
+
+def film_linear_fwd(cond, wl, bl):
+    B, Cc = cond.shape
+    F2 = wl.shape[0]
+    gb = torch.empty((B, F2), dtype=torch.float32, device=cond.device)
+    call("hrseg_film_linear_fwd", ptr(cond), ptr(wl), ptr(bl), ptr(gb), B, Cc, F2)
+    return gb
+
+
+def film_linear_bwd(cond, wl, dgb, dwl, dbl, dcond_scale, want_dcond=True):
+    B, Cc = cond.shape
+    dcond = torch.empty((B, Cc), dtype=torch.float32, device=cond.device) if want_dcond else None
+    call("hrseg_film_linear_bwd", ptr(cond), ptr(wl), ptr(dgb), ptr(dcond), ptr(dwl), ptr(dbl), B, Cc, wl.shape[0],
+         float(dcond_scale))
+    return dcond
+
+
+def head_fwd(f, gb, w, bias):
+    """f NHWC [B,H,W,F]; w [Cout,F] storage; -> z NHWC [B,H,W,Cout]"""
+    B, H, W, F = f.shape
+    Cout = w.shape[0]
+    z = empty_nhwc(B, H, W, Cout, f)
+    call("hrseg_head_fwd", ptr(f), _ld(f), ptr(gb), ptr(w), ptr(bias), ptr(z), Cout, B, H * W, F, Cout)
+    return z
+
+
+def head_bwd(f, gb, w, dz, dw, dbias, dgb, want_df=True, df=None, df_accumulate=False):
+    B, H, W, F = f.shape
+    Cout = w.shape[0]
+    if want_df and df is None:
+        df = torch.empty(f.shape, dtype=torch.float32, device=f.device)
+        df_accumulate = False
+    call("hrseg_head_bwd", ptr(f), _ld(f), ptr(gb), ptr(w), ptr(dz), _ld(dz), ptr(df), _ld(df) if df is not None else 0,
+         int(df_accumulate), ptr(dw), ptr(dbias), ptr(dgb), B, H * W, F, Cout)
+    return df
+
+
+def logits_up_fwd(z, Ho, Wo, align_corners=True):
+    B, Hi, Wi, Cn = z.shape
+    out = torch.empty((B, Cn, Ho, Wo), dtype=torch.float32, device=z.device)
+    call("hrseg_logits_up_fwd", ptr(z), _ld(z), B, Hi, Wi, Cn, ptr(out), Ho, Wo, int(align_corners))
+    return out
+
+
+def logits_up_bwd(dout, Hi, Wi, align_corners=True):
+    B, Cn, Ho, Wo = dout.shape
+    din = empty_nhwc(B, Hi, Wi, Cn, dout)
+    call("hrseg_logits_up_bwd", ptr(dout), B, Hi, Wi, Cn, ptr(din), Cn, Ho, Wo, int(align_corners))
+    return din
+
+
+def sigmoid_fwd(z):
+    p = torch.empty_like(z)
+    call("hrseg_sigmoid_fwd", ptr(z), ptr(p), z.numel())
+    return p
+
+
+def _strides3(dp, B, Cn, hw):
+    """(sb, sc, si) element strides of a [B,C,H,W]-shaped (possibly expanded) gradient."""
+    if dp.dim() == 4:
+        assert dp.stride(3) in (0, 1) and (dp.stride(2) == dp.shape[3] * dp.stride(3) or dp.shape[2] == 1)
+        return dp.stride(0), dp.stride(1), dp.stride(3)
+    assert dp.dim() == 2
+    return dp.stride(0), dp.stride(1), 0
+
+
+def sigmoid_bwd(dp, z, dz=None, accumulate=False):
+    B, Cn, H, W = z.shape
+    if dz is None:
+        dz = torch.empty_like(z)
+        accumulate = False
+    sb, sc, si = _strides3(dp, B, Cn, H * W)
+    call("hrseg_sigmoid_bwd", ptr(dp), sb, sc, si, ptr(z), ptr(dz), int(accumulate), B, Cn, H * W)
+    return dz
+
+
+def compose_fwd(z, pprev, group_parent, group_size):
+    B, Cn, H, W = z.shape
+    p = torch.empty_like(z)
+    call("hrseg_compose_fwd", ptr(z), ptr(pprev), ptr(p), B, Cn, pprev.shape[1], H * W, len(group_parent),
+         _lib.int_array(group_parent), _lib.int_array(group_size))
+    return p
+
+
+def compose_bwd(dp, z, pprev, group_parent, group_size, dz=None, dz_accumulate=False, dpprev=None,
+                dpprev_accumulate=False, want_dz=True, want_dpprev=True):
+    B, Cn, H, W = z.shape
+    if want_dz and dz is None:
+        dz, dz_accumulate = torch.empty_like(z), False
+    if want_dpprev and dpprev is None:
+        dpprev, dpprev_accumulate = torch.empty_like(pprev), False
+    sb, sc, si = _strides3(dp, B, Cn, H * W)
+    call("hrseg_compose_bwd", ptr(dp), sb, sc, si, ptr(z), ptr(pprev), ptr(dz), int(dz_accumulate), ptr(dpprev),
+         int(dpprev_accumulate), B, Cn, pprev.shape[1], H * W, len(group_parent), _lib.int_array(group_parent),
+         _lib.int_array(group_size))
+    return dz, dpprev
+
+
+# ------------------------------------------------------------------ loss / metrics / optimizer
+def loss_fwd(z, t, w):
+    """-> (out[3] = ce, dice, n_valid_dice ; coef for the backward)"""
+    B, Cn, H, W = z.shape
+    part = torch.empty(B * Cn * 5, dtype=torch.float64, device=z.device)
+    out = torch.empty(3, dtype=torch.float32, device=z.device)
+    coef = torch.empty(B * Cn * 4, dtype=torch.float32, device=z.device)
+    call("hrseg_loss_partials", ptr(z), ptr(t), ptr(part), B, Cn, H * W)
+    call("hrseg_loss_finalize", ptr(part), ptr(w), B, Cn, ptr(out), ptr(coef))
+    return out, coef
+
+
+def loss_bwd(z, t, coef, g, dz=None, accumulate=False):
+    B, Cn, H, W = z.shape
+    if dz is None:
+        dz, accumulate = torch.empty_like(z), False
+    call("hrseg_loss_bwd", ptr(z), ptr(t), ptr(coef), ptr(g), ptr(dz), int(accumulate), B, Cn, H * W)
+    return dz
+
+
+def consistency_sums(p, pprev, group_parent, group_size):
+    """-> [ngroups] float64 sums of |sum_children P - P_parent| over batch and pixels"""
+    B, Cn, H, W = p.shape
+    out = torch.zeros(len(group_parent), dtype=torch.float64, device=p.device)
+    call("hrseg_consistency", ptr(p), ptr(pprev), ptr(out), B, Cn, pprev.shape[1], H * W, len(group_parent),
+         _lib.int_array(group_parent), _lib.int_array(group_size))
+    return out
+
+
+def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):
+    """-> (onehot or None, confusion matrix [K,K] int64 with K = C + child)"""
+    B, Cn, H, W = z.shape
+    K = Cn + (1 if child else 0)
+    onehot = torch.empty_like(z) if (want_onehot and mask_pred) else None
+    cm = torch.zeros((K, K), dtype=torch.int64, device=z.device)
+    call("hrseg_predict_metrics", ptr(z), ptr(t), ptr(onehot), ptr(cm), B, Cn, H * W, int(child), int(mask_pred))
+    return onehot, cm
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    call("hrseg_adamw", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+         float(wd), float(bc1), float(bc2), float(gscale))

@@ -1,0 +1,55 @@
+"""The C-ABI library loads, exports every symbol include/hrseg.h declares, and the ctypes
+prototypes in _lib.py agree with the header argument by argument (no compute calls: CPU only)."""
+import ctypes
+import os
+import re
+
+from tests.helpers import ROOT
+
+HEADER = os.path.join(ROOT, "include", "hrseg.h")
+
+
+def parse_header():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(hrseg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
+        decls[m.group(2)] = [] if args == ["void"] else args
+    return decls
+
+
+def ctype_of(arg):
+    if "*" in arg or "hrseg_stream_t" in arg:
+        return ctypes.c_void_p
+    base = arg.rsplit(" ", 1)[0].strip()
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}[base]
+
+
+def test_header_symbols_exported_and_prototypes_match():
+    from hrseg_amd import _lib
+    decls = parse_header()
+    assert len(decls) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name, args in decls.items():
+        assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
+        if name in ("hrseg_last_error_string", "hrseg_abi_version"):
+            continue
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+        want = [ctype_of(a) for a in args]
+        got = list(_lib.PROTOTYPES[name])
+        got = [ctypes.c_void_p if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t for t in got]
+        assert got == want, f"{name}: ctypes {got} != header {want}"
+    for name in _lib.PROTOTYPES:
+        assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
+    assert _lib.abi_version() == 1
+
+
+def test_invalid_arguments_are_reported_without_a_gpu():
+    from hrseg_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.hrseg_last_error_string.restype = ctypes.c_char_p
+    shape = _lib.ConvShape(B=1, Hi=8, Wi=8, Cin=16, ldx=16, Ho=7, Wo=8, Cout=16, ldy=16, ksize=3, stride=1)
+    rc = lib.hrseg_conv_fwd(None, None, None, None, ctypes.byref(shape), None)
+    assert rc == -1
+    assert b"does not match" in lib.hrseg_last_error_string()

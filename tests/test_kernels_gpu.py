@@ -1,0 +1,363 @@
+"""Every HIP entry point against a plain fp32 torch-CPU reference of the same op (through the
+C ABI, on the GPU).  Tolerances are relative to the reference's max magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hrseg_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+def nhwc(x):  # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(x):  # NHWC cuda -> NCHW cpu
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def store(w):  # [O,I,kh,kw] -> [O][kh*kw][I] storage
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+CONV_CASES = [
+    # Cin, Cout, k, s, H, W, B
+    (48, 48, 3, 1, 37, 41, 2), (64, 128, 3, 1, 20, 20, 2), (96, 96, 3, 1, 19, 23, 3), (256, 48, 3, 1, 16, 16, 1),
+    (48, 96, 3, 2, 31, 31, 2), (96, 192, 3, 2, 20, 18, 2), (64, 64, 3, 2, 33, 30, 2), (64, 256, 1, 1, 17, 17, 2),
+    (144, 144, 1, 1, 15, 15, 2), (96, 48, 1, 1, 9, 9, 2), (384, 384, 3, 1, 10, 10, 2), (128, 64, 3, 1, 24, 24, 1),
+    (192, 192, 3, 1, 39, 39, 4), (16, 32, 3, 1, 8, 8, 1), (3, 64, 3, 2, 30, 30, 2), (3, 64, 3, 1, 21, 17, 2),
+    (48, 48, 3, 1, 155, 155, 4),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    cin, cout, k, s, H, W, B = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, stride=s, padding=(k - 1) // 2)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+
+    xd, wd = nhwc(x), store(w)
+    y = ops.conv_fwd(xd, wd, bias.cuda(), k, s)
+    assert rel(nchw(y), y_ref) < 2e-5
+    dyd = nhwc(dy)
+    dw = torch.zeros_like(wd)
+    ops.conv_wgrad(xd, dyd, dw, k, s)
+    dw_nchw = dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
+    assert rel(dw_nchw, wr.grad) < 5e-5
+    # second call accumulates
+    ops.conv_wgrad(xd, dyd, dw, k, s)
+    assert rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), 2 * wr.grad) < 5e-5
+    if cin % 16 == 0:
+        wt = ops.weight_transpose(wd, cout, k * k, cin)
+        dx = ops.conv_dgrad(dyd, wt, xd.shape, k, s)
+        assert rel(nchw(dx), xr.grad) < 2e-5
+        ops.conv_dgrad(dyd, wt, xd.shape, k, s, out=dx, accumulate=True)
+        assert rel(nchw(dx), 2 * xr.grad) < 2e-5
+
+
+def test_conv_into_channel_slice(ops):
+    """output written into a channel slice of a wider NHWC buffer (concat without copy)"""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 12, 12, generator=g)
+    w = torch.randn(48, 32, 3, 3, generator=g) / 17
+    buf = torch.zeros(2, 12, 12, 112, device="cuda")
+    ops.conv_fwd(nhwc(x), store(w), None, 3, 1, out=buf[..., 64:112])
+    assert rel(nchw(buf[..., 64:112]), F.conv2d(x, w, padding=1)) < 2e-5
+    assert float(buf[..., :64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C,H,W,B,relu,res", [(48, 37, 41, 2, True, True), (64, 20, 20, 3, True, False),
+                                              (720, 9, 9, 2, False, False), (96, 31, 17, 2, False, True),
+                                              (1024, 5, 5, 2, True, False), (192, 13, 13, 1, True, True)])
+def test_batchnorm_train_fwd_bwd(ops, C, H, W, B, relu, res):
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    r = torch.randn(B, C, H, W, generator=g) if res else None
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z_ref = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if res:
+        z_ref = z_ref + rr
+    if relu:
+        z_ref = F.relu(z_ref)
+    dz = torch.randn(z_ref.shape, generator=g)
+    z_ref.backward(dz)
+
+    yd = nhwc(y)
+    rmd, rvd, nbt = rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device="cuda")
+    coef = ops.bn_train_coef(yd, gamma.cuda(), beta.cuda(), rmd, rvd, nbt, 0.1, 1e-5)
+    rd = nhwc(r) if res else None
+    z = ops.bn_apply(yd, coef, rd, relu)
+    assert rel(nchw(z), z_ref) < 1e-5
+    assert rel(rmd, rm_ref) < 1e-5 and rel(rvd, rv_ref) < 1e-5 and int(nbt) == 1
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dres = torch.empty_like(yd) if res else None
+    dy = ops.bn_bwd(nhwc(dz), z, relu, yd, coef, dgam, dbet, dres)
+    scale = float(yr.grad.abs().max())
+    assert float((nchw(dy) - yr.grad).abs().max()) < 2e-5 * max(scale, 1.0)
+    assert rel(dgam, gr.grad) < 2e-5 and rel(dbet, br.grad) < 2e-5
+    if res:
+        assert rel(nchw(dres), rr.grad) < 1e-6
+
+
+def test_batchnorm_eval_coef(ops):
+    C = 48
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(2, C, 7, 9, generator=g)
+    gamma, beta, rm, rv = torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5
+    coef = ops.bn_eval_coef(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    z = ops.bn_apply(nhwc(y), coef, None, False)
+    assert rel(nchw(z), F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(20, 20), (31, 17), (5, 8)])
+def test_maxpool(ops, H, W):
+    g = torch.Generator().manual_seed(H)
+    x = F.relu(torch.randn(2, 64, H, W, generator=g))      # many exact ties at 0, as after ReLU
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd = nhwc(x)
+    y = ops.maxpool2_fwd(xd)
+    assert torch.equal(nchw(y), y_ref.detach())
+    dx = ops.maxpool2_bwd(xd, nhwc(dy))
+    assert torch.equal(nchw(dx), xr.grad)
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,C", [(10, 10, 20, 20, 64), (20, 20, 155, 155, 48), (39, 39, 155, 155, 16),
+                                           (7, 9, 14, 18, 128), (1, 1, 4, 4, 16), (8, 8, 8, 8, 32)])
+def test_bilinear_align_corners(ops, Hi, Wi, Ho, Wo, C):
+    g = torch.Generator().manual_seed(Hi + Ho)
+    x = torch.randn(2, C, Hi, Wi, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd = nhwc(x)
+    out = torch.empty(2, Ho, Wo, C, device="cuda")
+    ops.bilinear_fwd(xd, out, Ho, Wo)
+    assert rel(nchw(out), y_ref) < 1e-5
+    dx = ops.bilinear_bwd(nhwc(dy), xd.shape, Ho, Wo)
+    assert rel(nchw(dx), xr.grad) < 1e-5
+
+
+def test_bilinear_pad_slice_accumulate(ops):
+    """UNet `up`: x2 upsample, zero pad to the skip size, written into the concat slice."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 7, 7, generator=g)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.pad(up, (0, 1, 0, 1))                         # 14 -> 15, diff//2 = 0 left/top
+    buf = torch.full((2, 15, 15, 64), 7.0, device="cuda")
+    ops.bilinear_fwd(nhwc(x), buf[..., 32:], 14, 14, 0, 0)
+    assert rel(nchw(buf[..., 32:]), ref) < 1e-5
+    assert float((buf[..., :32] - 7.0).abs().max()) == 0.0
+    dbuf = torch.randn(2, 15, 15, 64, device="cuda")
+    dx = ops.bilinear_bwd(dbuf[..., 32:], (2, 7, 7, 32), 14, 14, 0, 0)
+    xr = x.clone().requires_grad_(True)
+    F.pad(F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True), (0, 1, 0, 1)).backward(
+        nchw(dbuf[..., 32:]))
+    assert rel(nchw(dx), xr.grad) < 1e-5
+    # accumulate + relu (HRNet fuse sum)
+    base = torch.randn(2, 14, 14, 32, device="cuda")
+    out = base.clone()
+    ops.bilinear_fwd(nhwc(x), out, 14, 14, accumulate=True, relu=True)
+    assert rel(nchw(out), F.relu(nchw(base) + up)) < 1e-5
+
+
+def test_glue_kernels(ops):
+    a, b = torch.randn(2, 9, 9, 48, device="cuda"), torch.randn(2, 9, 9, 48, device="cuda")
+    assert torch.allclose(ops.add(a, b, relu=True), F.relu(a + b))
+    dst = torch.zeros(2, 9, 9, 96, device="cuda")
+    ops.copy(a, dst[..., 48:])
+    ops.copy(b, dst[..., 48:], accumulate=True)
+    assert torch.allclose(dst[..., 48:], a + b) and float(dst[..., :48].abs().max()) == 0
+    assert torch.equal(ops.relu_bwd(a, b), torch.where(b > 0, a, torch.zeros_like(a)))
+    x = torch.randn(2, 3, 11, 13)
+    assert torch.equal(ops.nchw_to_nhwc(x.cuda()).cpu(), x.permute(0, 2, 3, 1).contiguous())
+    z = torch.randn(2, 11, 13, 4, device="cuda")
+    assert torch.equal(ops.nhwc_to_nchw(z), z.permute(0, 3, 1, 2).contiguous())
+
+
+@pytest.mark.parametrize("F_,Cout,film", [(64, 4, True), (64, 7, False), (720, 4, True), (720, 3, True), (64, 2, True)])
+def test_head_fwd_bwd(ops, F_, Cout, film):
+    g = torch.Generator().manual_seed(F_ + Cout)
+    B, H, W = 2, 13, 11
+    f = torch.randn(B, F_, H, W, generator=g)
+    w = torch.randn(Cout, F_, generator=g) / F_ ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    gb = torch.randn(B, 2 * F_, generator=g) if film else None
+    fr, wr, br = f.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    gbr = gb.clone().requires_grad_(True) if film else None
+    fm = fr * gbr[:, :F_, None, None] + gbr[:, F_:, None, None] if film else fr
+    z_ref = F.conv2d(fm, wr[:, :, None, None], br)
+    dz = torch.randn(z_ref.shape, generator=g)
+    z_ref.backward(dz)
+    fd = nhwc(f)
+    gbd = gb.cuda() if film else None
+    z = ops.head_fwd(fd, gbd, w.cuda(), bias.cuda())
+    assert rel(nchw(z), z_ref) < 1e-5
+    dw, db = torch.zeros(Cout, F_, device="cuda"), torch.zeros(Cout, device="cuda")
+    dgb = torch.zeros(B, 2 * F_, device="cuda") if film else None
+    df = ops.head_bwd(fd, gbd, w.cuda(), nhwc(dz), dw, db, dgb)
+    assert rel(nchw(df), fr.grad) < 1e-5
+    assert rel(dw, wr.grad) < 2e-5 and rel(db, br.grad) < 2e-5
+    if film:
+        assert rel(dgb, gbr.grad) < 2e-5
+
+
+def test_logits_up(ops):
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(2, 4, 16, 16, generator=g)
+    zr = z.clone().requires_grad_(True)
+    ref = F.interpolate(zr, size=(62, 62), mode="bilinear", align_corners=True)
+    d = torch.randn(ref.shape, generator=g)
+    ref.backward(d)
+    out = ops.logits_up_fwd(nhwc(z), 62, 62)
+    assert rel(out, ref) < 1e-5
+    din = ops.logits_up_bwd(d.cuda(), 16, 16)
+    assert rel(nchw(din), zr.grad) < 1e-5
+
+
+def test_gap_film_linear(ops):
+    g = torch.Generator().manual_seed(1)
+    p = torch.rand(3, 4, 37, 29, generator=g)
+    cond = ops.gap_nchw(p.cuda())
+    assert rel(cond, p.mean((2, 3))) < 1e-6
+    wl, bl = torch.randn(128, 4, generator=g), torch.randn(128, generator=g)
+    cr, wr, br = p.mean((2, 3)).requires_grad_(True), wl.clone().requires_grad_(True), bl.clone().requires_grad_(True)
+    gb_ref = F.linear(cr, wr, br)
+    dgb = torch.randn(gb_ref.shape, generator=g)
+    gb_ref.backward(dgb)
+    gb = ops.film_linear_fwd(cond, wl.cuda(), bl.cuda())
+    assert rel(gb, gb_ref) < 1e-5
+    dwl, dbl = torch.zeros(128, 4, device="cuda"), torch.zeros(128, device="cuda")
+    dcond = ops.film_linear_bwd(cond, wl.cuda(), dgb.cuda(), dwl, dbl, 0.5)
+    assert rel(dcond, 0.5 * cr.grad) < 1e-5 and rel(dwl, wr.grad) < 1e-5 and rel(dbl, br.grad) < 1e-5
+
+
+def test_composition_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(2)
+    B, H, W = 2, 9, 7
+    z0 = torch.randn(B, 2, H, W, generator=g)
+    z1 = torch.randn(B, 5, H, W, generator=g)
+    z0r, z1r = z0.clone().requires_grad_(True), z1.clone().requires_grad_(True)
+    p0 = torch.sigmoid(z0r)
+    parts, start = [], 0
+    for parent, size in ((1, 2), (0, 3)):
+        pp = p0[:, parent:parent + 1]
+        q = torch.softmax(z1r[:, start:start + size] + torch.log(pp + 1e-6), 1)
+        parts.append(pp * q)
+        start += size
+    p1 = torch.cat(parts, 1)
+    d1 = torch.randn(p1.shape, generator=g)
+    p1.backward(d1)
+
+    p0d = ops.sigmoid_fwd(z0.cuda())
+    p1d = ops.compose_fwd(z1.cuda(), p0d, [1, 0], [2, 3])
+    assert rel(p0d, p0) < 1e-6 and rel(p1d, p1) < 1e-5
+    dz1, dp0 = ops.compose_bwd(d1.cuda(), z1.cuda(), p0d, [1, 0], [2, 3])
+    dz0 = ops.sigmoid_bwd(dp0, z0.cuda())
+    assert rel(dz1, z1r.grad) < 1e-5 and rel(dz0, z0r.grad) < 1e-5
+    # broadcast (GAP-style) gradient: [B,C] expanded over pixels, no materialisation
+    dc = torch.randn(B, 5, generator=g)
+    z1r.grad = None
+    z0r.grad = None
+    p0 = torch.sigmoid(z0r)
+    parts, start = [], 0
+    for parent, size in ((1, 2), (0, 3)):
+        pp = p0[:, parent:parent + 1]
+        parts.append(pp * torch.softmax(z1r[:, start:start + size] + torch.log(pp + 1e-6), 1))
+        start += size
+    (torch.cat(parts, 1) * dc[:, :, None, None]).sum().backward()
+    dz1b, dp0b = ops.compose_bwd(dc.cuda()[:, :, None, None].expand(B, 5, H, W), z1.cuda(), p0d, [1, 0], [2, 3])
+    assert rel(dz1b, z1r.grad) < 1e-5
+    assert rel(ops.sigmoid_bwd(dp0b, z0.cuda()), z0r.grad) < 1e-5
+
+
+def test_loss_against_golden_and_oracle(ops):
+    from oracle import losses as OL
+    from tests.helpers import load_golden
+    gold = load_golden("loss_cases")
+    w = [float(v) for v in gold["w"]]
+    z, t = torch.from_numpy(gold["z"]), torch.from_numpy(gold["t"])
+    out, coef = ops.loss_fwd(z.cuda(), t.cuda(), torch.tensor(w).cuda())
+    assert abs(float(out[0]) - gold["ce"]) < 2e-6 and abs(float(out[1]) - gold["dice"]) < 2e-6
+    dz = ops.loss_bwd(z.cuda(), t.cuda(), coef, torch.ones(2).cuda())
+    assert rel(dz, torch.from_numpy(gold["dz"])) < 2e-5
+    out2, _ = ops.loss_fwd(torch.from_numpy(gold["z_all"]).cuda(), torch.from_numpy(gold["t_all"]).cuda(),
+                           torch.tensor(w).cuda())
+    assert abs(float(out2[0]) - 1.0) < 1e-6 and float(out2[2]) == 0.0
+    # 7-class flat level, separate upstream gradients
+    g = torch.Generator().manual_seed(4)
+    z7 = torch.randn(2, 7, 33, 31, generator=g)
+    t7 = F.one_hot(torch.randint(0, 7, (2, 33, 31), generator=g), 7).permute(0, 3, 1, 2).float()
+    w7 = [0.0285, 1.5159, 0.9227, 1.4842, 0.2532, 1.0, 3.8021]
+    zr = z7.clone().requires_grad_(True)
+    ce, dice = OL.cross_entropy_loss(zr, t7, True, w7), OL.soft_dice_loss(zr, t7, True, w7)
+    (0.7 * ce + 1.3 * dice).backward()
+    out7, coef7 = ops.loss_fwd(z7.cuda(), t7.cuda(), torch.tensor(w7).cuda())
+    assert abs(float(out7[0]) - ce.item()) < 2e-6 and abs(float(out7[1]) - dice.item()) < 2e-6
+    dz7 = ops.loss_bwd(z7.cuda(), t7.cuda(), coef7, torch.tensor([0.7, 1.3]).cuda())
+    assert rel(dz7, zr.grad) < 2e-5
+
+
+def test_consistency_and_metrics(ops):
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(6)
+    B, H, W = 2, 21, 19
+    z0, z1 = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g)
+    lab = torch.randint(0, 7, (B, H, W), generator=g)
+    t0 = torch.stack([lab == 0, lab == 1, lab == 2, lab >= 3], 1).float()
+    t1 = torch.stack([lab == 3, lab == 4, lab == 5, lab == 6], 1).float()
+    t1 = torch.where((lab < 3)[:, None], torch.full_like(t1, -1.0), t1)
+    oh0, cm0 = ops.predict_metrics(z0.cuda(), t0.cuda(), child=False)
+    oh1, cm1 = ops.predict_metrics(z1.cuda(), t1.cuda(), child=True)
+    ref = OM.train_step_metrics([z0.numpy(), z1.numpy()], [t0.numpy(), t1.numpy()])
+    from hrseg_amd.Metrics.performance_metrics import metrics_from_confusion
+    for L, (cm, child) in enumerate(((cm0, False), (cm1, True))):
+        got = metrics_from_confusion(cm, child)
+        for k in OM.METRIC_NAMES:
+            assert np.allclose(got[k].cpu().numpy(), ref[k][4 * L:4 * L + 4], atol=1e-6), (L, k)
+    oh_ref = [np.where(t.numpy() == -1, 0.0, OM.one_hot_predictions(z.numpy())) for z, t in ((z0, t0), (z1, t1))]
+    assert np.array_equal(oh0.cpu().numpy(), oh_ref[0]) and np.array_equal(oh1.cpu().numpy(), oh_ref[1])
+    sums = ops.consistency_sums(oh1, oh0, [3], [4])
+    ref_c = np.abs(oh_ref[1].sum(1) - oh_ref[0][:, 3]).sum()
+    assert abs(float(sums[0]) - ref_c) < 1e-6
+
+
+def test_adamw_matches_torch(ops):
+    g = torch.Generator().manual_seed(8)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-3)
+    pd, m, v = p.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adamw(pd, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert rel(pd, pr.data) < 1e-6
