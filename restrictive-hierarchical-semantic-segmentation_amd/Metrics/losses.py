@@ -1,0 +1,128 @@
+"""Class-weighted CE + soft-Dice + hierarchy-consistency losses on the GPU.
+
+Call surface of the reference's Metrics/losses.py: ``CrossEntropyLoss(smooth)``,
+``SoftDiceLoss(smooth, num_classes)`` called as ``loss(outs, targets,
+logits_input=False, class_weight=None)`` and ``hierarchical_consistency_loss(
+probs_per_level, levels, parent_of, reduction='mean')``.
+
+One fused HIP pass over (logits, targets) (hrseg_loss_partials) produces the five
+masked per-(b,c) sums both losses need; the reference walks B*C boolean-mask
+gathers per loss (losses.py:52-59, :100-114), each a device->host sync.  The
+gradient is one more pass (hrseg_loss_bwd).  Semantics kept: mask = target != -1,
+CE item -> constant 1.0 when any class mask of the item is empty (:116), Dice
+items with 0/0 dropped (:64), Dice -> None when no item survives (:66).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_weight_cache = {}
+
+
+def _weights(class_weight, device):
+    if class_weight is None:
+        # the reference fails here too (losses.py:56-59 / :103-112)
+        raise TypeError("class_weight is required: the reference losses index it per class")
+    key = (tuple(float(v) for v in class_weight), str(device))
+    w = _weight_cache.get(key)
+    if w is None:
+        w = torch.tensor(key[0], dtype=torch.float32, device=device)
+        _weight_cache[key] = w
+    return w
+
+
+class _FusedLoss(torch.autograd.Function):
+    """(logits, targets, w) -> [ce, dice, n_valid_dice_items]"""
+
+    @staticmethod
+    def forward(ctx, z, t, w):
+        z = z.contiguous()
+        t = t.contiguous()
+        out, coef = ops.loss_fwd(z, t, w)
+        ctx.save_for_backward(z, t, coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, t, coef = ctx.saved_tensors
+        return ops.loss_bwd(z, t, coef, g.contiguous()), None, None
+
+
+def fused_ce_dice(logits, targets, class_weight):
+    """-> tensor [3] = (CE, Dice, number of valid Dice items); differentiable w.r.t. logits."""
+    if logits.shape[1] != len(class_weight):
+        raise ValueError(f"class_weight has {len(class_weight)} entries, logits have {logits.shape[1]} channels")
+    return _FusedLoss.apply(logits, targets, _weights(class_weight, logits.device))
+
+
+def _as_logits(outs, logits_input, log_domain):
+    """The kernels take logits.  Already-normalised inputs are mapped back:
+    log-probabilities are their own logits; probabilities go through log()."""
+    if logits_input or log_domain:
+        return outs
+    return torch.log(outs)
+
+
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, smooth=0.0):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, outs, targets, logits_input=False, class_weight=None):
+        return fused_ce_dice(_as_logits(outs, logits_input, True), targets, class_weight)[0]
+
+
+class SoftDiceLoss(nn.Module):
+    def __init__(self, smooth=0, num_classes=3):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, outs, targets, logits_input=False, class_weight=None):
+        res = fused_ce_dice(_as_logits(outs, logits_input, False), targets, class_weight)
+        if float(res[2]) == 0.0:          # every item was 0/0: the reference returns None
+            return None
+        return res[1]
+
+
+def _level_groups(levels, parent_of, L):
+    """[(parent channel at L-1, [child channels at L])] for parents that have children at L"""
+    out = []
+    for p_idx, p_name in enumerate(levels[L - 1]):
+        ch = [i for i, c in enumerate(levels[L]) if parent_of.get(c, None) == p_name]
+        if ch:
+            out.append((p_idx, ch))
+    return out
+
+
+def hierarchical_consistency_loss(probs_per_level, levels, parent_of, reduction="mean"):
+    """mean_{b,h,w} |sum_children P_c - P_p| averaged over parents (losses.py:150-177).
+
+    Forward on the GPU (hrseg_consistency).  In the training loop the inputs are
+    one-hot predictions and carry no gradient; inputs that require
+    grad are rejected rather than silently detached."""
+    if probs_per_level is None or levels is None or parent_of is None:
+        return probs_per_level[0].sum() * 0 if probs_per_level else 0.0
+    if any(p.requires_grad for p in probs_per_level):
+        raise NotImplementedError("hierarchical_consistency_loss: gradient w.r.t. probabilities is not built; "
+                                  "pass detached probabilities (the reference loop passes one-hot predictions)")
+    total, count = None, 0
+    for L in range(1, len(levels)):
+        groups = _level_groups(levels, parent_of, L)
+        if not groups:
+            continue
+        prev, cur = probs_per_level[L - 1], probs_per_level[L]
+        contiguous = all(ch == list(range(ch[0], ch[0] + len(ch))) for _, ch in groups) and \
+            [c for _, ch in groups for c in ch] == list(range(cur.shape[1]))
+        if not contiguous:
+            raise NotImplementedError("children of a parent must occupy consecutive channels (BFS channel order)")
+        sums = ops.consistency_sums(cur, prev, [p for p, _ in groups], [len(ch) for _, ch in groups])
+        n = cur.shape[0] * cur.shape[2] * cur.shape[3]
+        part = sums.sum() / n if reduction == "mean" else sums.sum()
+        total = part if total is None else total + part
+        count += len(groups)
+    if count == 0:
+        return probs_per_level[0].sum() * 0
+    return (total / count).float()

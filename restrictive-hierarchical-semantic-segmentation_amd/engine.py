@@ -1,0 +1,283 @@
+"""Execution engine of the hot path: flat parameter storage, a forward recorder and
+a hand-rolled reverse pass that launches the HIP kernels (ops.py).
+
+Why not torch.autograd per op: a hierarchical HRNet step is ~5,000 kernel
+launches; the engine keeps the bookkeeping to a Python list of closures, lets
+weight gradients accumulate straight into one flat fp32 gradient buffer (the
+L backbone passes add into the same slots, the RCCL all-reduce and the fused
+AdamW run over that one buffer) and frees activations as the reverse pass
+consumes them.  torch.autograd sees the whole model as ONE node
+(Models/models.py:_Bridge), so ``loss.backward()`` of the reference loop works.
+
+Activations are NHWC fp32 (`Act.data`), possibly a channel slice of a wider
+tensor.  Gradient buffers are exclusively owned by one Act (no aliasing), so
+in-place accumulation is always safe.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class Act:
+    """An activation and its gradient slot."""
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data, needs_grad=True):
+        self.data = data
+        self.grad = None
+        self.needs_grad = needs_grad
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class FlatParams:
+    """All parameters of a module as views of one flat fp32 buffer (+ a flat gradient).
+
+    Conv weights keep their logical [Cout,Cin,kh,kw] shape but live in OHWI order
+    (channels_last strides), which is what the conv kernels read; state_dict()
+    and load_state_dict() keep working on the logical shape.
+    """
+
+    def __init__(self, module, device):
+        self.device = device
+        params = [(n, p) for n, p in module.named_parameters()]
+        sizes = [p.numel() for _, p in params]
+        # every slot starts on a 16-byte boundary (vector loads of weights/bias)
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += (s + 3) // 4 * 4
+        self.numel = total
+        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.slots = {}
+        self.params = []
+        with torch.no_grad():
+            for (name, p), off, n in zip(params, offs, sizes):
+                store = self.data[off:off + n]
+                gstore = self.grad[off:off + n]
+                if p.dim() == 4:
+                    o, i, kh, kw = p.shape
+                    store.view(o, kh, kw, i).copy_(p.detach().permute(0, 2, 3, 1).to(device))
+                    view = store.view(o, kh, kw, i).permute(0, 3, 1, 2)
+                    gview = gstore.view(o, kh, kw, i).permute(0, 3, 1, 2)
+                else:
+                    store.view(p.shape).copy_(p.detach().to(device))
+                    view, gview = store.view(p.shape), gstore.view(p.shape)
+                p.data = view
+                p._hr_store, p._hr_gstore, p._hr_gview = store, gstore, gview
+                p._hr_range = (off, off + n)
+                self.slots[name] = (off, n)
+                self.params.append(p)
+        self._first, self._last = self.params[0], self.params[-1]
+        self.grads_fresh = True   # flat grad is all zeros
+
+    def valid(self, device):
+        """False once .to()/.cuda() rebound the parameters to fresh storages."""
+        return (self.device == device and self._first.data_ptr() == self.data.data_ptr()
+                and self._last._hr_store.data_ptr() == self._last.data_ptr())
+
+    def attach_grads(self):
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != p._hr_gview.data_ptr():
+                p.grad = p._hr_gview
+
+    def prepare_backward(self):
+        """zero_grad(set_to_none=True) detaches the views: the flat gradient then restarts from zero."""
+        if self._first.grad is None and not self.grads_fresh:
+            self.grad.zero_()
+        self.grads_fresh = False
+
+
+class Recorder:
+    """Forward launcher + tape of backward closures for ONE model forward."""
+
+    def __init__(self, training, record):
+        self.training = training
+        self.record = record
+        self.tape = []
+        self.wt_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _push(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    def mark(self, label):
+        """a named position in the tape (DDP bucket boundaries)"""
+        self._push(label)
+
+    def backward(self, hook=None):
+        """run the tape in reverse; str entries are marks handed to `hook`."""
+        while self.tape:
+            fn = self.tape.pop()
+            if isinstance(fn, str):
+                if hook is not None:
+                    hook(fn)
+            else:
+                fn()
+
+    def _wt(self, conv):
+        key = id(conv)
+        wt = self.wt_cache.get(key)
+        if wt is None:
+            co, ci, kh, kw = conv.weight.shape
+            wt = ops.weight_transpose(conv.weight._hr_store, co, kh * kw, ci)
+            self.wt_cache[key] = wt
+        return wt
+
+    @staticmethod
+    def _give(act, g):
+        """hand a freshly written gradient tensor to `act` (first contribution)"""
+        act.grad = g
+
+    # ------------------------------------------------------------------ conv + BN (+residual) (+ReLU)
+    def conv_bn(self, x, conv, bn, relu, residual=None, out=None):
+        k, s = conv.kernel_size[0], conv.stride[0]
+        bias = conv.bias._hr_store if conv.bias is not None else None
+        y = ops.conv_fwd(x.data, conv.weight._hr_store, bias, k, s)
+        if self.training:
+            coef = ops.bn_train_coef(y, bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked, bn.momentum, bn.eps)
+        else:
+            coef = ops.bn_eval_coef(bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var, bn.eps)
+        z = Act(ops.bn_apply(y, coef, residual.data if residual is not None else None, relu, out=out))
+        if not self.record:
+            return z
+        eval_mode = not self.training
+
+        def bwd():
+            dz = z.grad
+            z.grad = None
+            dres, dres_acc = None, False
+            if residual is not None and residual.needs_grad:
+                if residual.grad is None:
+                    residual.grad = torch.empty(residual.data.shape, dtype=torch.float32, device=dz.device)
+                else:
+                    dres_acc = True
+                dres = residual.grad
+            dy = ops.bn_bwd(dz, z.data, relu, y, coef, bn.weight._hr_gstore, bn.bias._hr_gstore, dres, dres_acc,
+                            eval_mode, dy_out=dz)
+            ops.conv_wgrad(x.data, dy, conv.weight._hr_gstore, k, s)
+            if x.needs_grad:
+                if x.grad is None:
+                    x.grad = ops.conv_dgrad(dy, self._wt(conv), x.data.shape, k, s)
+                else:
+                    ops.conv_dgrad(dy, self._wt(conv), x.data.shape, k, s, out=x.grad, accumulate=True)
+        self._push(bwd)
+        return z
+
+    # ------------------------------------------------------------------ pooling
+    def maxpool2(self, x):
+        y = Act(ops.maxpool2_fwd(x.data))
+        if self.record:
+            def bwd():
+                g = y.grad
+                y.grad = None
+                if x.grad is None:
+                    x.grad = ops.maxpool2_bwd(x.data, g)
+                else:
+                    ops.maxpool2_bwd(x.data, g, dx=x.grad, accumulate=True)
+            self._push(bwd)
+        return y
+
+    # ------------------------------------------------------------------ UNet `up`: upsample x2, pad, concat
+    def up_concat(self, low, skip, align_corners=True):
+        B, Hs, Ws, Cs = skip.data.shape
+        _, Hl, Wl, Cl = low.data.shape
+        Hr, Wr = 2 * Hl, 2 * Wl
+        py, px = (Hs - Hr) // 2, (Ws - Wr) // 2
+        buf = ops.empty_nhwc(B, Hs, Ws, Cs + Cl, skip.data)
+        ops.copy(skip.data, buf[..., :Cs])
+        ops.bilinear_fwd(low.data, buf[..., Cs:], Hr, Wr, py, px, align_corners)
+        cat = Act(buf)
+        if self.record:
+            def bwd():
+                g = cat.grad
+                cat.grad = None
+                if skip.grad is None:
+                    skip.grad = torch.empty(skip.data.shape, dtype=torch.float32, device=g.device)
+                    ops.copy(g[..., :Cs], skip.grad)
+                else:
+                    ops.copy(g[..., :Cs], skip.grad, accumulate=True)
+                if low.grad is None:
+                    low.grad = ops.bilinear_bwd(g[..., Cs:], low.data.shape, Hr, Wr, py, px, align_corners)
+                else:
+                    ops.bilinear_bwd(g[..., Cs:], low.data.shape, Hr, Wr, py, px, align_corners, din=low.grad,
+                                     accumulate=True)
+            self._push(bwd)
+        return cat
+
+    # ------------------------------------------------------------------ HRNet fuse: relu(sum of terms)
+    def fuse_sum(self, terms, align_corners=True):
+        """terms: list of (Act, is_lowres); same-res terms are added, low-res ones bilinearly
+        upsampled into the sum; ReLU on the result (Models/models.py:527-542)."""
+        same = [a for a, low in terms if not low]
+        lows = [a for a, low in terms if low]
+        ref = same[0]
+        B, H, W, Cn = ref.data.shape
+        if len(same) >= 2:
+            out = ops.add(same[0].data, same[1].data, relu=(len(same) == 2 and not lows))
+            for i, a in enumerate(same[2:]):
+                ops.add(out, a.data, relu=(i == len(same) - 3 and not lows), out=out)
+        else:
+            out = torch.empty(ref.data.shape, dtype=torch.float32, device=ref.data.device)
+            ops.copy(ref.data, out)
+        for i, a in enumerate(lows):
+            ops.bilinear_fwd(a.data, out, H, W, 0, 0, align_corners, accumulate=True, relu=(i == len(lows) - 1))
+        y = Act(out)
+        if self.record:
+            def bwd():
+                g = ops.relu_bwd(y.grad, y.data, out=y.grad)
+                y.grad = None
+                for a in lows:
+                    if a.grad is None:
+                        a.grad = ops.bilinear_bwd(g, a.data.shape, H, W, 0, 0, align_corners)
+                    else:
+                        ops.bilinear_bwd(g, a.data.shape, H, W, 0, 0, align_corners, din=a.grad, accumulate=True)
+                for i, a in enumerate(same):
+                    if a.grad is not None:
+                        ops.copy(g, a.grad, accumulate=True)
+                    elif i == len(same) - 1:
+                        a.grad = g                      # last reader takes the buffer itself
+                    else:
+                        a.grad = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+                        ops.copy(g, a.grad)
+            self._push(bwd)
+        return y
+
+    # ------------------------------------------------------------------ HRNet head concat (models.py:743-747)
+    def upsample_concat(self, xs, align_corners=True):
+        B, H, W, _ = xs[0].data.shape
+        chans = [x.data.shape[3] for x in xs]
+        buf = ops.empty_nhwc(B, H, W, sum(chans), xs[0].data)
+        ops.copy(xs[0].data, buf[..., :chans[0]])
+        off = chans[0]
+        for x, c in zip(xs[1:], chans[1:]):
+            ops.bilinear_fwd(x.data, buf[..., off:off + c], H, W, 0, 0, align_corners)
+            off += c
+        cat = Act(buf)
+        if self.record:
+            def bwd():
+                g = cat.grad
+                cat.grad = None
+                o = 0
+                for i, (x, c) in enumerate(zip(xs, chans)):
+                    gs = g[..., o:o + c]
+                    if i == 0:
+                        if x.grad is None:
+                            x.grad = torch.empty(x.data.shape, dtype=torch.float32, device=g.device)
+                            ops.copy(gs, x.grad)
+                        else:
+                            ops.copy(gs, x.grad, accumulate=True)
+                    elif x.grad is None:
+                        x.grad = ops.bilinear_bwd(gs, x.data.shape, H, W, 0, 0, align_corners)
+                    else:
+                        ops.bilinear_bwd(gs, x.data.shape, H, W, 0, 0, align_corners, din=x.grad, accumulate=True)
+                    o += c
+            self._push(bwd)
+        return cat

@@ -316,8 +316,14 @@ def compose_bwd(dp, z, pprev, group_parent, group_size, dz=None, dz_accumulate=F
 
 
 # ------------------------------------------------------------------ loss / metrics / optimizer
+def _c(t):
+    """NCHW planes are addressed as b*C*hw + c*hw + i: insist on contiguous storage"""
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def loss_fwd(z, t, w):
     """-> (out[3] = ce, dice, n_valid_dice ; coef for the backward)"""
+    z, t = _c(z), _c(t)
     B, Cn, H, W = z.shape
     part = torch.empty(B * Cn * 5, dtype=torch.float64, device=z.device)
     out = torch.empty(3, dtype=torch.float32, device=z.device)
@@ -328,6 +334,7 @@ def loss_fwd(z, t, w):
 
 
 def loss_bwd(z, t, coef, g, dz=None, accumulate=False):
+    z, t = _c(z), _c(t)
     B, Cn, H, W = z.shape
     if dz is None:
         dz, accumulate = torch.empty_like(z), False
@@ -337,6 +344,7 @@ def loss_bwd(z, t, coef, g, dz=None, accumulate=False):
 
 def consistency_sums(p, pprev, group_parent, group_size):
     """-> [ngroups] float64 sums of |sum_children P - P_parent| over batch and pixels"""
+    p, pprev = _c(p), _c(pprev)
     B, Cn, H, W = p.shape
     out = torch.zeros(len(group_parent), dtype=torch.float64, device=p.device)
     call("hrseg_consistency", ptr(p), ptr(pprev), ptr(out), B, Cn, pprev.shape[1], H * W, len(group_parent),
@@ -346,6 +354,7 @@ def consistency_sums(p, pprev, group_parent, group_size):
 
 def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):
     """-> (onehot or None, confusion matrix [K,K] int64 with K = C + child)"""
+    z, t = _c(z), _c(t)
     B, Cn, H, W = z.shape
     K = Cn + (1 if child else 0)
     onehot = torch.empty_like(z) if (want_onehot and mask_pred) else None

@@ -1,0 +1,132 @@
+"""Product models / losses / train step on the GPU against (a) the golden vectors generated from
+the reference and (b) the CPU oracle on the same seeded inputs.  Bar: 1e-3 relative (fp32),
+as BASELINE.json's north_star states."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _args(kind, hier, num_classes, weights, batch):
+    return argparse.Namespace(model_type=1 if hier else 0, model_select=0 if kind == "unet" else 1,
+                              num_classes=num_classes, level_weights=weights, level0_pretrain_epochs=None,
+                              batch_size=batch)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_model_matches_reference_golden(name):
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    model = build_model(PM, kind, hier, tree, size).cuda()
+    assert [n for n, _ in model.named_parameters()] == list(g["grad_names"])
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    num_classes = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    args = _args(kind, hier, num_classes, weights, batch)
+
+    model.eval()
+    with torch.no_grad():
+        _, logits = PT._model_call(model, x, args, tree)
+    logits = logits if hier else [logits]
+    for L, z in enumerate(logits):
+        assert rel_err(z.cpu().numpy(), g[f"eval_logits{L}"]) < TOL, f"eval logits {L}"
+
+    model.train()
+    probs, logits = PT._model_call(model, x, args, tree)
+    logits = logits if hier else [logits]
+    targets = PT.split_targets(target, args)
+    loss = 0.0
+    onehots = []
+    for L, (z, t) in enumerate(zip(logits, targets)):
+        assert rel_err(z.detach().cpu().numpy(), g[f"logits{L}"]) < TOL, f"logits {L}"
+        res = PL.fused_ce_dice(z, t, weights[L])
+        assert abs(float(res[0]) - g[f"ce{L}"]) < TOL * max(1.0, abs(g[f"ce{L}"]))
+        assert abs(float(res[1]) - g[f"dice{L}"]) < TOL * max(1.0, abs(g[f"dice{L}"]))
+        loss = loss + res[0] + res[1]
+        from hrseg_amd import ops
+        oh, _ = ops.predict_metrics(z.detach(), t, child=(L > 0), mask_pred=True)
+        # arg-max ties/near-ties can flip a pixel: allow a 1e-3 fraction of disagreeing pixels
+        assert float((oh.cpu() != torch.from_numpy(g[f"onehot{L}"])).float().mean()) < 1e-3
+        onehots.append(oh)
+    if hier:
+        for L, p in enumerate(probs):
+            assert rel_err(p.detach().cpu().numpy(), g[f"probs{L}"]) < TOL, f"probs {L}"
+        cons = PL.hierarchical_consistency_loss(onehots, model.levels, model.parent_of)
+        assert abs(float(cons) - g["cons_onehot"]) < 2e-3
+        cons_p = PL.hierarchical_consistency_loss([p.detach() for p in probs], model.levels, model.parent_of)
+        assert abs(float(cons_p) - g["cons_probs"]) < 1e-5
+        loss = loss + torch.tensor(float(g["cons_onehot"]), device="cuda")
+    assert abs(float(loss) - g["loss"]) < TOL * abs(g["loss"])
+
+    loss.backward()
+    named = dict(model.named_parameters())
+    norms = np.array([0.0 if p.grad is None else float(p.grad.double().norm()) for p in named.values()])
+    ref = g["grad_norms"]
+    scale = np.maximum(ref, 1e-2 * ref.max())
+    worst = np.argmax(np.abs(norms - ref) / scale)
+    assert np.abs(norms - ref)[worst] / scale[worst] < 5e-3, (list(named)[worst], norms[worst], ref[worst])
+    for key in g.files:
+        if key.startswith("grad::"):
+            got = named[key[6:]].grad.cpu().numpy()
+            assert np.abs(got - g[key]).max() < 5e-3 * np.abs(g[key]).max() + 1e-6, key
+    bufs = np.array([float(b.double().norm()) for _, b in model.named_buffers()])
+    assert np.max(np.abs(bufs - g["buf_norms"]) / np.maximum(g["buf_norms"], 1e-6)) < TOL
+
+
+@pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64"])
+def test_train_steps_track_the_oracle(name):
+    """two full train steps (fwd, metrics, loss, bwd, AdamW) next to the CPU oracle"""
+    from oracle import models as OM
+    from oracle import train_step as OT
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    num_classes = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    args = _args(kind, hier, num_classes, weights, batch)
+    x, target = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+
+    om = build_model(OM, kind, hier, tree, size)
+    oopt = torch.optim.AdamW(om.parameters(), lr=1e-4)
+    pm = build_model(PM, kind, hier, tree, size).cuda()
+    popt = PT.FusedAdamW(pm, lr=[1e-4])
+    loss_fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in num_classes]
+    pm.train()
+    level_loss = []
+    for step in range(2):
+        ref = OT.train_step(om, oopt, x, target, num_classes, weights, hierarchical=hier, is_unet=(kind == "unet"))
+        loss, cms = PT.train_step(pm, popt, x.cuda(), target.cuda(), loss_fns, args, tree, level_loss)
+        assert abs(float(loss) - ref["loss"].item()) < TOL * abs(ref["loss"].item()), f"step {step}"
+        vec = PT._metric_vectors(cms)
+        for k, v in ref["metrics"].items():
+            assert np.allclose(vec[k].cpu().numpy(), v, atol=2e-3), (step, k)
+    # parameters after two AdamW steps
+    osd = om.state_dict()
+    for n, p in pm.state_dict().items():
+        a, b = p.detach().cpu().double(), osd[n].double()
+        if n.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 2 * (2 if hier else 1)
+            continue
+        assert float((a - b).abs().max()) < 2e-4 + 1e-3 * float(b.abs().max()), n
+
+
+def test_missing_library_is_loud(tmp_path, monkeypatch):
+    """the product path has no CPU fallback: CPU tensors are rejected"""
+    from hrseg_amd.Models import models as PM
+    tree = load_tree("class_tree_tl.json")
+    m = PM.UNet(size=32, n_channels=3, hierarchy=tree, model_type=1)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32), type=1)
