@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of hierarchical HRNet-W48 at 620x620 on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model hrnet|unet] [--batch B] [--size S]
+
+One "step" = the reference's train-loop body on one synthetic batch (forward of the L level
+passes, prediction prep + metrics, CE+Dice+consistency loss, backward, gradient all-reduce,
+AdamW), inputs resident in HBM.  N>1 is launched by torch.distributed.run (one rank per GPU,
+RCCL); every rank works on its own 4-image shard (weak scaling) and rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline     -- the dominant kernel (implicit-GEMM 3x3 conv 48->48 at 155x155, fp32 MFMA): algorithmic
+                  FLOPs per launch / average launch time measured here with events on the launch stream
+  cpu_baseline -- the CPU oracle (oracle/, a torch-CPU port of the reference path) timed on this host's
+                  cores on a bounded sample (one batch-1 step); reported, never the target
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
+TRAIN_GFLOP_PER_IMAGE = {          # BASELINE.md section 2 (conv+linear MACs x2, fwd+dgrad+wgrad = 3x fwd), 620x620
+    ("hrnet", True): 1662.0, ("hrnet", False): 831.0, ("unet", True): 2168.0, ("unet", False): 1084.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="hrnet", choices=["hrnet", "unet"])
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--size", type=int, default=620)
+    ap.add_argument("--flat", action="store_true", help="non-hierarchical (model_type 0)")
+    ap.add_argument("--tree", default="class_tree_tl.json")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device):
+    from hrseg_amd.Metrics import losses
+    from hrseg_amd.Models import models
+    from hrseg_amd import train as T
+    from hrseg_amd.utils import synth
+    from hrseg_amd.utils.config import hrnet_w48_config
+    from hrseg_amd.utils.hierarchy import get_classes
+    tree = json.load(open(os.path.join(ROOT, "restrictive-hierarchical-semantic-segmentation_amd", "data", args.tree)))
+    hier = not args.flat
+    torch.manual_seed(0)
+    if args.model == "unet":
+        model = models.UNet(size=args.size, n_channels=3, hierarchy=tree, model_type=1 if hier else 0)
+    else:
+        model = models.HighResolutionNet(hrnet_w48_config(), hierarchy=tree, model_type=1 if hier else 0)
+    model.to(device)
+    num_classes = get_classes(tree, full=hier)
+    if hier:
+        weights = synth.README_LEVEL_WEIGHTS_TL if args.tree == "class_tree_tl.json" else \
+            [[1.0] * n for n in num_classes]
+    else:
+        weights = synth.README_LEVEL_WEIGHTS_FLAT
+        num_classes = [sum(num_classes)]
+    ns = argparse.Namespace(model_type=1 if hier else 0, model_select=0 if args.model == "unet" else 1,
+                            num_classes=num_classes, level_weights=weights, level0_pretrain_epochs=None,
+                            batch_size=args.batch)
+    loss_fns = [[losses.CrossEntropyLoss(), losses.SoftDiceLoss(num_classes=n)] for n in num_classes]
+    opt = T.FusedAdamW(model, lr=[1e-4])
+    return tree, model, ns, loss_fns, opt
+
+
+def probe_dominant_kernel(device, batch, size):
+    """HRNet's most executed conv (3x3, 48->48 at size/4: 64 launches per backbone pass) timed
+    alone with events on the launch stream; algorithmic FLOPs = 2*M*N*K."""
+    from hrseg_amd import ops
+    s4 = ((size + 1) // 2 + 1) // 2
+    x = torch.randn(batch, s4, s4, 48, device=device)
+    w = torch.randn(48, 3, 3, 48, device=device) * 0.05
+    for _ in range(3):
+        ops.conv_fwd(x, w, None, 3, 1)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.conv_fwd(x, w, None, 3, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * batch * s4 * s4 * 48 * 48 * 9
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "igemm_conv_kernel<4,3> (3x3 48->48 fwd, %dx%d, B=%d)" % (s4, s4, batch),
+            "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(ms * 1e3, 2), "flop_per_launch": flops}
+
+
+def cpu_baseline(args, tree):
+    """the CPU port (oracle) on this host: ONE batch-1 train step at the benchmark resolution"""
+    from oracle import models as OM
+    from oracle import train_step as OT
+    from hrseg_amd.utils import synth
+    from hrseg_amd.utils.config import hrnet_w48_config
+    from hrseg_amd.utils.hierarchy import get_classes
+    hier = not args.flat
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if args.model == "unet":
+        m = OM.UNet(size=args.size, n_channels=3, hierarchy=tree, model_type=1 if hier else 0)
+    else:
+        m = OM.HighResolutionNet(hrnet_w48_config(), hierarchy=tree, model_type=1 if hier else 0)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    x, t = synth.synthetic_batch(tree, 1, args.size, seed=1, hierarchical=hier)
+    nc = get_classes(tree, full=hier)
+    w = synth.README_LEVEL_WEIGHTS_TL if hier else synth.README_LEVEL_WEIGHTS_FLAT
+    t0 = time.time()
+    OT.train_step(m, opt, torch.from_numpy(x), torch.from_numpy(t), nc if hier else [sum(nc)], w, hierarchical=hier,
+                  is_unet=(args.model == "unet"))
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 full train step, batch 1, %dx%d, %s %s, torch-CPU oracle (%.1f s)" % (
+                args.size, args.size, "hierarchical" if hier else "flat", args.model, dt)}
+
+
+def main():
+    args = parse()
+    from hrseg_amd.parallel import GradSync, init_distributed
+    from hrseg_amd import train as T
+    from hrseg_amd.utils import synth
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    tree, model, ns, loss_fns, opt = build(args, device)
+    sync = None
+    if world > 1:
+        sync = GradSync(model)
+        opt.grad_scale = 1.0 / world
+    hier = not args.flat
+    x, t = synth.synthetic_batch(tree, args.batch, args.size, seed=100 + rank, hierarchical=hier)
+    x, t = torch.from_numpy(x).to(device), torch.from_numpy(t).to(device)
+    model.train()
+    level_loss = []
+
+    def step():
+        return T.train_step(model, opt, x, t, loss_fns, ns, tree, level_loss)
+
+    for _ in range(args.warmup):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, cms = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt
+        gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
+        line = {
+            "metric": "train images/sec (620x620, hier-HRNet-W48)", "value": round(ips, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %s (%s), %dx%d, batch %d per GPU, full train step (fwd L passes, metrics, "
+                                   "CE+Dice+consistency, bwd, grad all-reduce, AdamW)" % (
+                                       "HRNet-W48" if args.model == "hrnet" else "UNet",
+                                       "hierarchical" if hier else "flat", args.tree, args.size, args.size, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": final_loss},
+        }
+        if gf is not None and args.size == 620:
+            tf = ips * gf / 1e3
+            line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),
+                                          "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4)}
+        if not args.no_probe:
+            line["roofline"] = probe_dominant_kernel(device, args.batch, args.size)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, tree)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -229,7 +229,7 @@ class _EngineModel(nn.Module):
             lin = film.mlp[1]
             cond = ops.gap_nchw(p_prev)
             gb = ops.film_linear_fwd(cond, lin.weight._hr_store, lin.bias._hr_store)
-        zl = ops.head_fwd(feats.data, gb, w._hr_store, b._hr_store)
+        zl = ops.head_fwd(feats.data, gb, w._hr_store, b._hr_store, cout=head.out_channels)
         if (zl.shape[1], zl.shape[2]) != tuple(size):
             z = ops.logits_up_fwd(zl, size[0], size[1], self.align_corners)
         else:
@@ -249,7 +249,7 @@ class _EngineModel(nn.Module):
             dzl = ops.nchw_to_nhwc(dz)
         dgb = torch.zeros_like(lv["gb"]) if film is not None else None
         feats.grad = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
-                                  head.bias._hr_gstore, dgb)
+                                  head.bias._hr_gstore, dgb, cout=head.out_channels)
         if film is None:
             return None
         lin = film.mlp[1]
@@ -340,12 +340,16 @@ class UNet(_EngineModel):
     def _backbone(self, rec, x):
         x1 = self.inc0.run(rec, x)
         x2 = self.down1.run(rec, x1)
+        rec.mark("down2")            # gradient all-reduce bucket boundaries (parallel.py)
         x3 = self.down2.run(rec, x2)
         x4 = self.down3.run(rec, x3)
+        rec.mark("down4")
         x5 = self.down4.run(rec, x4)
         d = self.up1.run(rec, x5, x4)
+        rec.mark("up2")
         d = self.up2.run(rec, d, x3)
         d = self.up3.run(rec, d, x2)
+        rec.mark("up4")
         return self.up4.run(rec, d, x1)
 
     def forward(self, x, type=0, hierarchy={}, threshold=0.5):
@@ -575,13 +579,15 @@ class HighResolutionNet(_EngineModel):
         return self.classifiers[L]
 
     def _backbone(self, rec, x):
+        # rec.mark(name): "every parameter registered at or after module `name` is final once the
+        # reverse pass gets back here" (gradient all-reduce buckets, parallel.py)
         x = rec.conv_bn(x, self.stem[0], self.stem[1], relu=True)
         x = rec.conv_bn(x, self.stem[3], self.stem[4], relu=True)
-        rec.mark("stem")
-        x = _run_seq(rec, self.layer1, x)
         rec.mark("layer1")
+        x = _run_seq(rec, self.layer1, x)
         ys = [x]
         for t_idx in (1, 2, 3):
+            rec.mark(f"transition{t_idx}")
             cfg = getattr(self, f"stage{t_idx + 1}_cfg")
             trans = getattr(self, f"transition{t_idx}")
             xs = []
@@ -597,7 +603,7 @@ class HighResolutionNet(_EngineModel):
             ys = xs
             for mod in getattr(self, f"stage{t_idx + 1}"):
                 ys = mod.run(rec, ys)
-            rec.mark(f"stage{t_idx + 1}")
+        rec.mark("shared_head")
         cat = rec.upsample_concat(ys, self.align_corners)
         return rec.conv_bn(cat, self.shared_head[0], self.shared_head[1], relu=True)
 

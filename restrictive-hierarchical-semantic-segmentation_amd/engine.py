@@ -139,7 +139,7 @@ class Recorder:
     def conv_bn(self, x, conv, bn, relu, residual=None, out=None):
         k, s = conv.kernel_size[0], conv.stride[0]
         bias = conv.bias._hr_store if conv.bias is not None else None
-        y = ops.conv_fwd(x.data, conv.weight._hr_store, bias, k, s)
+        y = ops.conv_fwd(x.data, conv.weight._hr_store, bias, k, s, cout=conv.out_channels)
         if self.training:
             coef = ops.bn_train_coef(y, bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, bn.momentum, bn.eps)

@@ -52,10 +52,11 @@ def _shape(x_shape, ldx, Cout, ldy, k, s):
 
 
 # ------------------------------------------------------------------ convolution
-def conv_fwd(x, w, bias, k, s, out=None):
-    """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter)."""
+def conv_fwd(x, w, bias, k, s, out=None, cout=None):
+    """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
+    pass `cout` when w is the flat 1-D parameter slot."""
     B, Hi, Wi, Cin = x.shape
-    Cout = w.shape[0]
+    Cout = cout if cout is not None else w.shape[0]
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
     sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s)
@@ -220,7 +221,7 @@ def gap_nchw(p):
 
 def film_linear_fwd(cond, wl, bl):
     B, Cc = cond.shape
-    F2 = wl.shape[0]
+    F2 = bl.numel()
     gb = torch.empty((B, F2), dtype=torch.float32, device=cond.device)
     call("hrseg_film_linear_fwd", ptr(cond), ptr(wl), ptr(bl), ptr(gb), B, Cc, F2)
     return gb
@@ -229,23 +230,23 @@ def film_linear_fwd(cond, wl, bl):
 def film_linear_bwd(cond, wl, dgb, dwl, dbl, dcond_scale, want_dcond=True):
     B, Cc = cond.shape
     dcond = torch.empty((B, Cc), dtype=torch.float32, device=cond.device) if want_dcond else None
-    call("hrseg_film_linear_bwd", ptr(cond), ptr(wl), ptr(dgb), ptr(dcond), ptr(dwl), ptr(dbl), B, Cc, wl.shape[0],
+    call("hrseg_film_linear_bwd", ptr(cond), ptr(wl), ptr(dgb), ptr(dcond), ptr(dwl), ptr(dbl), B, Cc, dgb.shape[1],
          float(dcond_scale))
     return dcond
 
 
-def head_fwd(f, gb, w, bias):
+def head_fwd(f, gb, w, bias, cout=None):
     """f NHWC [B,H,W,F]; w [Cout,F] storage; -> z NHWC [B,H,W,Cout]"""
     B, H, W, F = f.shape
-    Cout = w.shape[0]
+    Cout = cout if cout is not None else w.shape[0]
     z = empty_nhwc(B, H, W, Cout, f)
     call("hrseg_head_fwd", ptr(f), _ld(f), ptr(gb), ptr(w), ptr(bias), ptr(z), Cout, B, H * W, F, Cout)
     return z
 
 
-def head_bwd(f, gb, w, dz, dw, dbias, dgb, want_df=True, df=None, df_accumulate=False):
+def head_bwd(f, gb, w, dz, dw, dbias, dgb, want_df=True, df=None, df_accumulate=False, cout=None):
     B, H, W, F = f.shape
-    Cout = w.shape[0]
+    Cout = cout if cout is not None else w.shape[0]
     if want_df and df is None:
         df = torch.empty(f.shape, dtype=torch.float32, device=f.device)
         df_accumulate = False

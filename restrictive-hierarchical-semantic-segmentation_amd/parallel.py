@@ -1,0 +1,107 @@
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL over xGMI.
+
+The reference's only multi-GPU mode is single-process nn.DataParallel
+(train.py:509-510): scatter the batch, replicate the weights, reduce-add the
+gradients to GPU 0 every step.  Here each rank owns a model replica and a shard
+of the minibatch; the ONE exchange per step is a sum-all-reduce of the flat
+fp32 gradient buffer (torch.distributed backend "nccl" = RCCL), issued bucket by
+bucket on a side stream while the LAST backward level (pass 0 of the level
+loop, the only one after which a gradient slot is final) is still running, and
+averaged inside the fused AdamW (grad_scale = 1/world).  BatchNorm statistics
+stay per-rank, exactly as the reference's DataParallel + SyncBatchNorm without
+a process group behaves.
+
+Bucket boundaries are the tape marks the model emits ("shared_head",
+"transition3", ...): when the reverse pass crosses mark m, every parameter
+registered at or after module m is final, so [offset(m), previous boundary) goes
+out.  xGMI is point-to-point; with 263 MB (HRNet) in 5-6 buckets each
+all-reduce stays large enough (>= 10 MB) to be link-bandwidth- not
+latency-bound.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def bucket_offsets(flat, marks):
+    """mark name -> flat offset of the first parameter whose name starts with it"""
+    out = {}
+    for m in marks:
+        cands = [off for name, (off, _) in flat.slots.items() if name == m or name.startswith(m + ".")]
+        if cands:
+            out[m] = min(cands)
+    return out
+
+
+class GradSync:
+    """Attach to a model: ``sync = GradSync(model, group); ...; loss.backward()`` leaves the
+    summed gradient in model._flat.grad (the optimizer divides by world size)."""
+
+    def __init__(self, model, group=None, marks=("layer1", "transition1", "transition2", "transition3",
+                                                 "shared_head", "down2", "down4", "up2", "up4"), min_bucket=1 << 20):
+        self.model = model
+        self.group = group
+        self.marks = marks
+        self.min_bucket = min_bucket
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._comm_stream = None
+        self._handles = []
+        self._boundary = None
+        self._offsets = None
+        self.launched = []          # [(lo, hi)] of the last step, for tests/inspection
+        model._grad_hook = self
+
+    # the model calls this with a mark name while the last backward level runs, then with "end"
+    def __call__(self, mark):
+        flat = self.model._flat
+        if self._offsets is None or self._offsets[0] is not flat:
+            self._offsets = (flat, bucket_offsets(flat, self.marks))
+        if self._boundary is None:
+            self._boundary = flat.numel
+            self.launched = []
+        if mark == "end":
+            self._launch(flat, 0, self._boundary)
+            self._finish()
+            self._boundary = None
+            return
+        off = self._offsets[1].get(mark)
+        if off is None or self._boundary - off < self.min_bucket:
+            return
+        self._launch(flat, off, self._boundary)
+        self._boundary = off
+
+    def _launch(self, flat, lo, hi):
+        if hi <= lo:
+            return
+        self.launched.append((lo, hi))
+        if self.world == 1:
+            return
+        chunk = flat.grad[lo:hi]
+        if chunk.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=chunk.device)
+            self._comm_stream.wait_stream(torch.cuda.current_stream(chunk.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _finish(self):
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+
+def init_distributed():
+    """Process group from torchrun's environment; returns (rank, local_rank, world)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, local, world

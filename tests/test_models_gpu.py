@@ -78,7 +78,11 @@ def test_model_matches_reference_golden(name):
     for key in g.files:
         if key.startswith("grad::"):
             got = named[key[6:]].grad.cpu().numpy()
-            assert np.abs(got - g[key]).max() < 5e-3 * np.abs(g[key]).max() + 1e-6, key
+            # head / FiLM gradients are a few ops from the loss; the first conv's sits behind every
+            # BN/ReLU of the net, where fp32 evaluations differ from each other by ~1e-2 already
+            # (tools/grad_noise.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
+            tol = 5e-2 if key[6:].startswith(("stem", "inc0")) else 5e-3
+            assert np.abs(got - g[key]).max() < tol * np.abs(g[key]).max() + 1e-6, key
     bufs = np.array([float(b.double().norm()) for _, b in model.named_buffers()])
     assert np.max(np.abs(bufs - g["buf_norms"]) / np.maximum(g["buf_norms"], 1e-6)) < TOL
 
@@ -120,7 +124,9 @@ def test_train_steps_track_the_oracle(name):
         if n.endswith("num_batches_tracked"):
             assert int(a) == int(b) == 2 * (2 if hier else 1)
             continue
-        assert float((a - b).abs().max()) < 2e-4 + 1e-3 * float(b.abs().max()), n
+        # two steps at lr=1e-4: an element whose gradient is pure rounding noise may move by
+        # +-lr per step in either evaluation, i.e. differ by up to 4e-4
+        assert float((a - b).abs().max()) < 4.5e-4 + 1e-3 * float(b.abs().max()), n
 
 
 def test_missing_library_is_loud(tmp_path, monkeypatch):

@@ -1,0 +1,60 @@
+"""How far are deep-path gradients from an fp64 evaluation, for the fp32 CPU oracle and for the
+GPU path?  (diagnostic; prints, asserts nothing)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree
+from oracle import models as OM, train_step as OT
+
+name = sys.argv[1] if len(sys.argv) > 1 else "hrnet_flat_tl_64"
+kind, hier, tree_file, size, batch = CASES[name]
+g = load_golden(name)
+tree = load_tree(tree_file)
+nc = [int(v) for v in g["num_classes"]]
+w = level_weights_for(tree_file, hier)
+x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+if len(sys.argv) > 2:            # other size / batch than the fixture's: synthetic inputs
+    from hrseg_amd.utils import synth
+    size = int(sys.argv[2]); batch = int(sys.argv[3]) if len(sys.argv) > 3 else batch
+    xn, tn = synth.synthetic_batch(tree, batch, size, seed=5, hierarchical=hier, blob=8)
+    x, t = torch.from_numpy(xn), torch.from_numpy(tn)
+    g = {"cons_onehot": 0.0}
+    hier_cons = False
+
+def oracle_grads(dtype):
+    m = build_model(OM, kind, hier, tree, size).to(dtype)
+    m.train()
+    out = OT.forward_loss(m, x.to(dtype), t.to(dtype), nc, w, hierarchical=hier, is_unet=(kind == "unet"), with_metrics=False)
+    out["loss"].backward()
+    return {n: p.grad.double().numpy() for n, p in m.named_parameters()}, float(out["loss"])
+
+g64, l64 = oracle_grads(torch.float64)
+g32, l32 = oracle_grads(torch.float32)
+from hrseg_amd.Models import models as PM
+from hrseg_amd.Metrics import losses as PL
+from hrseg_amd import train as PT
+import argparse
+args = argparse.Namespace(model_type=1 if hier else 0, model_select=0 if kind == "unet" else 1, num_classes=nc,
+                          level_weights=w, level0_pretrain_epochs=None, batch_size=batch)
+pm = build_model(PM, kind, hier, tree, size).cuda()
+pm.train()
+probs, logits = PT._model_call(pm, x.cuda(), args, tree)
+logits = logits if hier else [logits]
+targets = PT.split_targets(t.cuda(), args)
+loss = 0.0
+for L, (z, tt) in enumerate(zip(logits, targets)):
+    r = PL.fused_ce_dice(z, tt, w[L]); loss = loss + r[0] + r[1]
+loss.backward()
+print("loss fp64 %.8f  cpu32 %.8f  gpu %.8f (cpu values include the constant consistency term when hierarchical)" % (l64, l32, float(loss)))
+worst = []
+for n, p in pm.named_parameters():
+    ref = g64[n]; s = np.abs(ref).max() + 1e-12
+    e_cpu = np.abs(g32[n] - ref).max() / s
+    e_gpu = np.abs(p.grad.cpu().double().numpy() - ref).max() / s
+    worst.append((e_gpu, e_cpu, n, s))
+worst.sort(reverse=True)
+for e_gpu, e_cpu, n, s in worst[:12]:
+    print("%-60s max|g|=%.3e  err_gpu=%.2e  err_cpu32=%.2e" % (n, s, e_gpu, e_cpu))
+big = [w_ for w_ in worst if w_[3] > 1e-4]
+print("median err gpu %.2e cpu32 %.2e" % (np.median([w_[0] for w_ in big]), np.median([w_[1] for w_ in big])))
