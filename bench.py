@@ -102,6 +102,19 @@ def probe_dominant_kernel(device, batch, size):
             "avg_launch_us": round(ms * 1e3, 2), "flop_per_launch": flops}
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota
+    (os.cpu_count() reports the whole host, 256 on the GPU boxes with a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, tree):
     """the CPU port (oracle) on this host: ONE batch-1 train step at the benchmark resolution"""
     from oracle import models as OM
@@ -110,7 +123,7 @@ def cpu_baseline(args, tree):
     from hrseg_amd.utils.config import hrnet_w48_config
     from hrseg_amd.utils.hierarchy import get_classes
     hier = not args.flat
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     if args.model == "unet":
         m = OM.UNet(size=args.size, n_channels=3, hierarchy=tree, model_type=1 if hier else 0)
@@ -153,8 +166,18 @@ def main():
     def step():
         return T.train_step(model, opt, x, t, loss_fns, ns, tree, level_loss)
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    log("model on %s, %d params; warmup %d, steps %d" % (device, sum(p.numel() for p in model.parameters()),
+                                                          args.warmup, args.steps))
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         loss, _ = step()
+        torch.cuda.synchronize()
+        log("warmup step %d: %.3f s, loss %.5f, peak mem %.1f GB" % (i, time.perf_counter() - tw, float(loss),
+                                                                    torch.cuda.max_memory_allocated() / 2**30))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -189,9 +212,12 @@ def main():
             tf = ips * gf / 1e3
             line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),
                                           "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4)}
+        log("timed: %.3f s for %d steps" % (dt, args.steps))
         if not args.no_probe:
             line["roofline"] = probe_dominant_kernel(device, args.batch, args.size)
+            log("probe: %s" % json.dumps(line["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (one batch-1 oracle step on %d cores) ..." % host_cores())
             line["cpu_baseline"] = cpu_baseline(args, tree)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -98,7 +98,7 @@ int hrseg_bn_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, int 
                         double* partial, int nchunks, hrseg_stream_t stream);
 /* backward, phase 2: dgamma += sum g*xhat, dbeta += sum g (if not NULL);
  * dy = gamma*rstd*(g - mean_g - xhat*mean_gx); optionally dres (+)= g.
- * `sums` is scratch [2][C] fp32 filled here from the partials. */
+ * `partial` must hold (nchunks+1)*2*C doubles: the last [2][C] receives the totals. */
 int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int lddz,
                        const float* z, int ldz, int relu, const float* y, int ldy,
                        const float* coef, const float* gamma, float* dgamma, float* dbeta,

@@ -74,19 +74,42 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
-// coef: [0]=mean [1]=rstd [2]=scale [3]=shift
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchunks, long npix, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
-                                   float momentum, float eps, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    s += partial[((size_t)k * 2 + 0) * C + c];
-    ss += partial[((size_t)k * 2 + 1) * C + c];
-  }
+// Sum of partial[k][which][c] over chunks k for the block's 16 channels: 16 chunk lanes per
+// channel (a serial loop over up to 1024 chunks is a chain of dependent HBM-latency loads).
+// Returns the totals to the threads with lane==0 (tid < 16).
+__device__ __forceinline__ void reduce_chunks16(const double* __restrict__ partial, int nchunks, int C, int c,
+                                               double& s0, double& s1, double* red) {
+  const int lane = threadIdx.x >> 4;  // 0..15
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int k = lane; k < nchunks; k += 16) {
+      a += partial[((size_t)k * 2 + 0) * C + c];
+      b += partial[((size_t)k * 2 + 1) * C + c];
+    }
+  red[threadIdx.x * 2] = a;
+  red[threadIdx.x * 2 + 1] = b;
+  __syncthreads();
+  s0 = 0.0;
+  s1 = 0.0;
+  if (threadIdx.x < 16)
+    for (int l = 0; l < 16; ++l) {
+      s0 += red[(l * 16 + threadIdx.x) * 2];
+      s1 += red[(l * 16 + threadIdx.x) * 2 + 1];
+    }
+}
+
+// coef: [0]=mean [1]=rstd [2]=scale [3]=shift.  grid = ceil(C/16) blocks of 256 threads.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nchunks, long npix,
+                                                          int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, long long* nbt, float momentum,
+                                                          float eps, float* __restrict__ coef) {
+  __shared__ double red[512];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s, ss;
+  reduce_chunks16(partial, nchunks, C, c, s, ss, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (threadIdx.x >= 16 || c >= C) return;
   const double mean = s / (double)npix;
   double var = ss / (double)npix - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -176,18 +199,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// totals into partial[0][0..1][c] (in place), dgamma/dbeta accumulation
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ partial, int nchunks, int C, float* dgamma,
-                                       float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    s += partial[((size_t)k * 2 + 0) * C + c];
-    sx += partial[((size_t)k * 2 + 1) * C + c];
-  }
-  partial[c] = s;
-  partial[C + c] = sx;
+// totals -> totals[0..1][c] (a separate [2][C] area behind the partials), dgamma/dbeta accumulation
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial,
+                                                              double* __restrict__ totals, int nchunks, int C,
+                                                              float* dgamma, float* dbeta) {
+  __shared__ double red[512];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s, sx;
+  reduce_chunks16(partial, nchunks, C, c, s, sx, red);
+  if (threadIdx.x >= 16 || c >= C) return;
+  totals[c] = s;
+  totals[C + c] = sx;
   if (dgamma) dgamma[c] += (float)sx;
   if (dbeta) dbeta[c] += (float)s;
 }
@@ -494,7 +516,7 @@ extern "C" int hrseg_bn_finalize(const double* partial, int nchunks, long npix, 
                                  int64_t* num_batches_tracked, float momentum, float eps, float* coef,
                                  hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(partial && coef && C > 0 && nchunks > 0 && npix > 0, "hrseg_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, nchunks,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nchunks,
                      npix, C, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
                      coef);
   HRSEG_LAUNCH_CHECK("bn_finalize");
@@ -542,10 +564,12 @@ extern "C" int hrseg_bn_bwd_apply(const double* partial, int nchunks, const floa
   HRSEG_CHECK_ARG(partial && dz && y && coef && dy && (!relu || z) && npix > 0 && nchunks > 0,
                   "hrseg_bn_bwd_apply: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (double*)partial, nchunks, C,
+  // totals live behind the nchunks partial slabs: the caller sizes `partial` as (nchunks+1)*2*C
+  double* totals = (double*)partial + (size_t)nchunks * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, totals, nchunks, C,
                      dgamma, dbeta);
   HRSEG_LAUNCH_CHECK("bn_bwd_finalize");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, st, partial, dz, lddz, z, ldz, relu,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, st, totals, dz, lddz, z, ldz, relu,
                      y, ldy, coef, dy, lddy, dres, lddres, dres_accumulate, npix, C, eval_mode);
   HRSEG_LAUNCH_CHECK("bn_bwd_apply");
   return 0;

@@ -92,7 +92,7 @@ def weight_transpose(w_store, Cout, taps, Cin, out=None):
 def _nchunks(npix, Cn):
     q = Cn // 4
     p = 1 if q >= 256 else 256 // q
-    return max(1, min(1024, npix // (8 * p)))
+    return max(1, min(256, npix // (8 * p)))
 
 
 def bn_train_coef(y, gamma, beta, running_mean, running_var, nbt, momentum, eps):
@@ -126,7 +126,7 @@ def bn_bwd(dz, z, relu, y, coef, dgamma, dbeta, dres=None, dres_accumulate=False
     """-> dy (gradient w.r.t. the conv output); dgamma/dbeta accumulate; dres (+)= g."""
     Cn, npix = y.shape[3], _npix(y)
     nch = _nchunks(npix, Cn)
-    part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
+    part = torch.empty((nch + 1) * 2 * Cn, dtype=torch.float64, device=y.device)   # + totals [2][C]
     dy = dy_out if dy_out is not None else torch.empty(y.shape, dtype=torch.float32, device=y.device)
     zz = z if relu else None
     call("hrseg_bn_bwd_reduce", ptr(dz), _ld(dz), ptr(zz), _ld(z) if relu else 0, int(relu), ptr(y), _ld(y), ptr(coef),
