@@ -1,0 +1,59 @@
+"""Gradient-sync bucket logic with world_size 2 on CPU (gloo): every flat-gradient element is
+all-reduced exactly once, in reverse registration order, as the marks of the last backward level pass."""
+import os
+import types
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _fake_model(rank):
+    names = ["stem.0.weight", "layer1.0.conv1.weight", "transition1.0.0.weight", "stage2.0.w", "transition2.2.0.0.weight",
+             "stage3.0.w", "transition3.3.0.0.weight", "stage4.0.w", "shared_head.0.weight", "classifiers.0.weight",
+             "films.0.mlp.1.weight"]
+    sizes = [100, 3000, 2000, 5000, 1500, 9000, 2500, 12000, 4000, 60, 40]
+    slots, off = {}, 0
+    for n, s in zip(names, sizes):
+        slots[n] = (off, s)
+        off += s
+    flat = types.SimpleNamespace(slots=slots, numel=off, grad=torch.arange(off, dtype=torch.float32) * (rank + 1))
+    return types.SimpleNamespace(_flat=flat, _grad_hook=None)
+
+
+def _worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hrseg_amd.parallel import GradSync
+    model = _fake_model(rank)
+    sync = GradSync(model, min_bucket=1000)
+    assert model._grad_hook is sync
+    for step in range(2):
+        model._flat.grad = torch.arange(model._flat.numel, dtype=torch.float32) * (rank + 1)
+        # the reverse pass of the last level crosses the marks in this order
+        for mark in ("shared_head", "transition3", "transition2", "transition1", "layer1", "end"):
+            sync(mark)
+        expect = torch.arange(model._flat.numel, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        assert torch.equal(model._flat.grad, expect), f"rank {rank} step {step}"
+        # contiguous, non-overlapping, descending, complete
+        spans = sync.launched
+        assert spans[0][1] == model._flat.numel and spans[-1][0] == 0
+        for (lo, hi), (lo2, hi2) in zip(spans, spans[1:]):
+            assert hi2 == lo and lo2 < hi2
+        assert len(spans) >= 4
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_single_process_is_a_noop():
+    from hrseg_amd.parallel import GradSync
+    model = _fake_model(0)
+    before = model._flat.grad.clone()
+    sync = GradSync(model)
+    for mark in ("shared_head", "end"):
+        sync(mark)
+    assert torch.equal(model._flat.grad, before) and sync.launched[-1][0] == 0
