@@ -68,6 +68,9 @@ int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int accumulate
  * running gradient, zeroed by the caller at the start of a step). */
 int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
                      const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* tuning/debug: override the implicit-GEMM tile plan (0 = automatic) -- pixel tiles per wave
+ * (1,2,4), 16-channel K chunks per stage (1-3), LDS buffers (1,2), split-K factor */
+int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);
 /* wt[ci][t][co] = w[co][t][ci] */
 int hrseg_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin,
                            hrseg_stream_t stream);

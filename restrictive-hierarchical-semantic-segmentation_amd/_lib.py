@@ -80,6 +80,15 @@ _lib.hrseg_last_error_string.argtypes = []
 _lib.hrseg_abi_version.restype = _i
 _lib.hrseg_abi_version.argtypes = []
 
+_lib.hrseg_debug_set_conv_tune.restype = _i
+_lib.hrseg_debug_set_conv_tune.argtypes = [_i, _i, _i, _i]
+
+
+def set_conv_tune(wtm=0, kc=0, db=0, ksplit=0):
+    """tuning/debug override of the implicit-GEMM tile plan (0 = automatic)"""
+    _lib.hrseg_debug_set_conv_tune(wtm, kc, db, ksplit)
+
+
 _fn = {}
 for _name, _args in PROTOTYPES.items():
     f = getattr(_lib, _name)       # AttributeError here = header and library disagree

@@ -41,25 +41,39 @@ struct IgemmArgs {
 // group of a ds_read_b128 fragment read hits 16 distinct slots of the bank row
 __device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ ((-(row >> 2)) & 3); }
 
-template <int WTM, int WTN>
+// WTM x WTN 16x16 tiles per wave (4 waves split the pixel tile), KC 16-channel chunks per stage.
+// LDS stage image: A [KC][BM][16 floats], B [KC][BN][16 floats]; two stages (double buffer).
+// DB = LDS buffers: 2 = double buffer (one barrier per stage), 1 = single buffer (two barriers,
+// half the LDS, so more blocks per CU).  gridDim.y > 1 = split-K over the stage list: partial
+// sums are added with fp32 atomics.
+template <int WTM, int WTN, int KC, int DB>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
-  constexpr int BM = 64 * WTM;  // pixels per block (4 waves x WTM tiles x 16)
+  constexpr int BM = 64 * WTM;  // pixels per block
   constexpr int BN = 16 * WTN;  // channels per block
-  constexpr int A_LOADS = BM / 64;
-  constexpr int B_LOADS = (BN * 4 + 255) / 256;
-  constexpr int STAGE = (BM + BN) * 16;  // floats per LDS buffer
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int A_ROWS = BM / 64;
+  constexpr int B_F4 = BN * 4 * KC;
+  constexpr int B_LOADS = (B_F4 + 255) / 256;
+  constexpr int STAGE = (BM + BN) * 16 * KC;  // floats per LDS buffer
+  __shared__ __attribute__((aligned(16))) float lds[DB * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = p.N / BN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
 
+  // stage range of this block (split-K)
+  const int kchunks = p.K / (16 * KC);
+  const int nstages_all = p.ntaps * kchunks;
+  const int per = (nstages_all + gridDim.y - 1) / gridDim.y;
+  const int s_lo = blockIdx.y * per;
+  const int s_hi = min(s_lo + per, nstages_all);
+  const int nstages = s_hi - s_lo;
+
   // rows this thread stages: r = (tid>>2) + 64*i, 16-byte slot q = tid&3
   const int q = tid & 3;
-  int rpix[A_LOADS], riy[A_LOADS], rix[A_LOADS];
+  int rpix[A_ROWS], riy[A_ROWS], rix[A_ROWS];
 #pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
+  for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + (tid >> 2) + 64 * i;
     if (m < p.M) {
       const int b = m / (p.Ho * p.Wo);
@@ -74,52 +88,74 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
       rix[i] = 0;
     }
   }
-  const int kchunks = p.K >> 4;
-  const int nstages = p.ntaps * kchunks;
-
-  f32x4 ra[A_LOADS], rb[B_LOADS];
-  auto stage_load = [&](int s) {
-    const int t = s / kchunks, c0 = (s - t * kchunks) << 4;
-    const int oy = (int)((p.offy_pk >> (4 * t)) & 15) - 8;
-    const int ox = (int)((p.offx_pk >> (4 * t)) & 15) - 8;
-    const int wt = (int)((p.wtap_pk >> (4 * t)) & 15);
+  // LDS store offsets (constant per thread)
+  int a_st[A_ROWS], b_st[B_LOADS], b_row[B_LOADS], b_col[B_LOADS];
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
+  for (int i = 0; i < A_ROWS; ++i) {
+    const int r = (tid >> 2) + 64 * i;
+    a_st[i] = r * 16 + 4 * lds_slot(r, q);
+  }
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int f = tid + 256 * i;
+    const int j = f / (BN * 4), rem = f - j * (BN * 4);
+    const int r = rem >> 2, qq = rem & 3;
+    b_row[i] = r;
+    b_col[i] = 16 * j + 4 * qq;
+    b_st[i] = BM * 16 * KC + (j * BN + r) * 16 + 4 * lds_slot(r, qq);
+  }
+
+  // current tap / chunk
+  int t = s_lo / kchunks, c = s_lo - t * kchunks;
+  const float* aptr[A_ROWS];
+  bool aok[A_ROWS];
+  const float* bptr[B_LOADS];
+  auto set_tap = [&](int tap) {
+    const int oy = (int)((p.offy_pk >> (4 * tap)) & 15) - 8;
+    const int ox = (int)((p.offx_pk >> (4 * tap)) & 15) - 8;
+    const int wt = (int)((p.wtap_pk >> (4 * tap)) & 15);
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
       const int iy = riy[i] + oy, ix = rix[i] + ox;
-      const bool ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = (size_t)(rpix[i] + iy * p.Wi + ix) * p.ldx + c0 + 4 * q;
-        v = *reinterpret_cast<const f32x4*>(p.x + off);
-      }
-      ra[i] = v;
+      aok[i] = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      aptr[i] = p.x + (size_t)(aok[i] ? (rpix[i] + iy * p.Wi + ix) : 0) * p.ldx + 4 * q;
     }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int f = tid + 256 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < BN * 4) {
-        const size_t off = ((size_t)(n0 + (f >> 2)) * p.T + wt) * p.K + c0 + 4 * (f & 3);
-        v = *reinterpret_cast<const f32x4*>(p.w + off);
+    for (int i = 0; i < B_LOADS; ++i) bptr[i] = p.w + ((size_t)(n0 + b_row[i]) * p.T + wt) * p.K + b_col[i];
+  };
+
+  f32x4 ra[A_ROWS][KC], rb[B_LOADS];
+  auto stage_load = [&]() {   // loads stage (t, c), then advances (t, c)
+    const int c0 = c * 16 * KC;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i)
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (aok[i]) v = *reinterpret_cast<const f32x4*>(aptr[i] + c0 + 16 * j);
+        ra[i][j] = v;
       }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (tid + 256 * i < B_F4) v = *reinterpret_cast<const f32x4*>(bptr[i] + c0);
       rb[i] = v;
+    }
+    if (++c == kchunks) {
+      c = 0;
+      ++t;
+      if (t < p.ntaps) set_tap(t);
     }
   };
   auto stage_store = [&](int buf) {
     float* base = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int r = (tid >> 2) + 64 * i;
-      *reinterpret_cast<f32x4*>(base + r * 16 + 4 * lds_slot(r, q)) = ra[i];
-    }
+    for (int i = 0; i < A_ROWS; ++i)
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int f = tid + 256 * i;
-      if (f < BN * 4) {
-        const int r = f >> 2;
-        *reinterpret_cast<f32x4*>(base + BM * 16 + r * 16 + 4 * lds_slot(r, f & 3)) = rb[i];
-      }
-    }
+      for (int j = 0; j < KC; ++j) *reinterpret_cast<f32x4*>(base + j * BM * 16 + a_st[i]) = ra[i][j];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      if (tid + 256 * i < B_F4) *reinterpret_cast<f32x4*>(base + b_st[i]) = rb[i];
   };
 
   f32x4 acc[WTN][WTM];
@@ -132,33 +168,41 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
   const int frow = lane & 15;
   const int foff = frow * 16 + 4 * lds_slot(frow, lane >> 4);
 
-  stage_load(0);
-  stage_store(0);
+  if (nstages > 0) {
+    set_tap(t);
+    stage_load();
+    stage_store(0);
+  }
   __syncthreads();
   for (int s = 0; s < nstages; ++s) {
     const bool more = s + 1 < nstages;
-    if (more) stage_load(s + 1);
-    const float* base = lds + (s & 1) * STAGE;
-    f32x4 xf[WTM], wf[WTN];
+    if (more) stage_load();
+    const float* base = lds + ((DB == 2) ? (s & 1) : 0) * STAGE;
 #pragma unroll
-    for (int m = 0; m < WTM; ++m)
-      xf[m] = *reinterpret_cast<const f32x4*>(base + (wave * 16 * WTM + 16 * m) * 16 + foff);
+    for (int j = 0; j < KC; ++j) {
+      f32x4 xf[WTM], wf[WTN];
 #pragma unroll
-    for (int n = 0; n < WTN; ++n)
-      wf[n] = *reinterpret_cast<const f32x4*>(base + BM * 16 + (16 * n) * 16 + foff);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
+      for (int m = 0; m < WTM; ++m)
+        xf[m] = *reinterpret_cast<const f32x4*>(base + (j * BM + wave * 16 * WTM + 16 * m) * 16 + foff);
 #pragma unroll
       for (int n = 0; n < WTN; ++n)
+        wf[n] = *reinterpret_cast<const f32x4*>(base + BM * 16 * KC + (j * BN + 16 * n) * 16 + foff);
 #pragma unroll
-        for (int m = 0; m < WTM; ++m)
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
-    if (more) stage_store((s + 1) & 1);
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int n = 0; n < WTN; ++n)
+#pragma unroll
+          for (int m = 0; m < WTM; ++m)
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
+    }
+    if (DB == 1) __syncthreads();  // every wave is done reading before the buffer is rewritten
+    if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
     __syncthreads();
   }
 
   // epilogue: lane holds channels n0+16n+4g..+3 of pixel row (lane&15)
   const int g = lane >> 4;
+  const bool split = gridDim.y > 1;
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
     const int row = m0 + wave * 16 * WTM + 16 * m + (lane & 15);
@@ -172,33 +216,83 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
     for (int n = 0; n < WTN; ++n) {
       const int ch = n0 + 16 * n + 4 * g;
       f32x4 v = acc[n][m];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
-      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
-      *reinterpret_cast<f32x4*>(yrow + ch) = v;
+      if (p.bias && blockIdx.y == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (split) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
+      } else {
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        *reinterpret_cast<f32x4*>(yrow + ch) = v;
+      }
     }
   }
 }
 
-// zero-fill of output pixels a stride-2 dgrad never visits is not needed: the
-// four parity classes cover every input pixel (a class with no tap in range
-// still writes zeros because its loads are predicated off).
-
-template <int WTM, int WTN>
-static int launch_igemm(const IgemmArgs& a, hipStream_t st) {
+template <int WTM, int WTN, int KC, int DB>
+static void launch_igemm(const IgemmArgs& a, int ksplit, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 16 * WTN;
   const int grid = ceil_div(a.M, BM) * (a.N / BN);
-  hipLaunchKernelGGL((igemm_conv_kernel<WTM, WTN>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((igemm_conv_kernel<WTM, WTN, KC, DB>), dim3(grid, ksplit), dim3(256), 0, st, a);
+}
+
+// debug/tuning override (0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
+static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
+extern "C" int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit) {
+  g_tune_wtm = wtm; g_tune_kc = kc; g_tune_db = db; g_tune_ksplit = ksplit;
   return 0;
 }
 
+struct IgemmPlan { int wtm, wtn, kc, db, ksplit; };
+
+static IgemmPlan plan_igemm(const IgemmArgs& a) {
+  IgemmPlan pl;
+  // measured on MI355X (tools/conv_sweep.py): a single LDS buffer (more blocks per CU) beats double
+  // buffering everywhere; large problems want 128-pixel tiles with 16-channel stages, small ones
+  // 64-pixel tiles with the widest stage; under 256 blocks split K.
+  pl.wtn = (a.N % 48 == 0) ? 3 : (a.N % 64 == 0) ? 4 : (a.N % 32 == 0) ? 2 : 1;
+  const int kc_max = (a.K % 48 == 0) ? 3 : (a.K % 32 == 0) ? 2 : 1;
+  const int ntn = a.N / (16 * pl.wtn);
+  const long blocks128 = (long)ceil_div(a.M, 128) * ntn;
+  const bool large = blocks128 >= 384;
+  pl.wtm = large ? 2 : 1;
+  pl.kc = large ? 1 : kc_max;
+  pl.db = 1;
+  pl.ksplit = 1;
+  const long blocks = (long)ceil_div(a.M, 64 * pl.wtm) * ntn;
+  const int nstages = a.ntaps * (a.K / (16 * pl.kc));
+  if (blocks < 256) {
+    pl.ksplit = (int)((448 + blocks - 1) / blocks);
+    if (pl.ksplit > nstages / 3) pl.ksplit = nstages / 3;
+  }
+  if (g_tune_wtm) pl.wtm = g_tune_wtm;
+  if (g_tune_kc && a.K % (16 * g_tune_kc) == 0) pl.kc = g_tune_kc;
+  if (g_tune_db) pl.db = g_tune_db;
+  if (g_tune_ksplit) pl.ksplit = g_tune_ksplit;
+  // split-K needs an output it may add into: accumulate mode, or a contiguous tensor it can zero
+  const int nst = a.ntaps * (a.K / (16 * pl.kc));
+  if (pl.ksplit > nst) pl.ksplit = nst;
+  if (pl.ksplit < 1) pl.ksplit = 1;
+  if (!(a.accumulate || (a.ldy == a.N && a.oys == 1 && a.oxs == 1))) pl.ksplit = 1;
+  return pl;
+}
+
 static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
-  // channel tile: 48 for 48-multiples (48,96,192,384,720), 64 for 64-multiples,
-  // else 16/32; pixel tile 256 when that still gives >= 2 blocks per CU.
-  const bool big = ((long)ceil_div(a.M, 256) * (a.N / ((a.N % 48 == 0) ? 48 : (a.N % 64 == 0) ? 64 : 16))) >= 512;
-  if (a.N % 48 == 0) return big ? launch_igemm<4, 3>(a, st) : launch_igemm<2, 3>(a, st);
-  if (a.N % 64 == 0) return big ? launch_igemm<4, 4>(a, st) : launch_igemm<2, 4>(a, st);
-  if (a.N % 32 == 0) return launch_igemm<2, 2>(a, st);
-  return launch_igemm<2, 1>(a, st);
+  IgemmPlan pl = plan_igemm(a);
+  if (pl.ksplit > 1 && !a.accumulate) {
+    if (hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.B * a.Hy * a.Wy * a.N, st) != hipSuccess) pl.ksplit = 1;
+  }
+#define IG4(M_, N_, K_, D_) \
+  if (pl.wtm == M_ && pl.wtn == N_ && pl.kc == K_ && pl.db == D_) { launch_igemm<M_, N_, K_, D_>(a, pl.ksplit, st); return 0; }
+#define IG3(M_, N_, K_) IG4(M_, N_, K_, 1) IG4(M_, N_, K_, 2)
+#define IG2(M_, N_) IG3(M_, N_, 1) IG3(M_, N_, 2) IG3(M_, N_, 3)
+#define IG1(M_) IG2(M_, 1) IG2(M_, 2) IG2(M_, 3) IG2(M_, 4)
+  IG1(1) IG1(2) IG1(4)
+#undef IG1
+#undef IG2
+#undef IG3
+#undef IG4
+  hrseg_set_error("igemm: no kernel for plan wtm=%d wtn=%d kc=%d db=%d", pl.wtm, pl.wtn, pl.kc, pl.db);
+  return HRSEG_ERR_UNSUPPORTED;
 }
 
 // --------------------------------------------------------------------------- direct conv, Cin <= 4
@@ -516,7 +610,7 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
-  dispatch_igemm(a, st);
+  if (int e = dispatch_igemm(a, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;
 }
@@ -541,7 +635,7 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
     int oy[9], ox[9], wtp[9];
     for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
     pack_taps(a, a.T, oy, ox, wtp);
-    dispatch_igemm(a, st);
+    if (int e = dispatch_igemm(a, st)) return e;
     HRSEG_LAUNCH_CHECK("igemm_conv(dgrad)");
     return 0;
   }
@@ -564,7 +658,7 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
       c.Ho = hc; c.Wo = wc; c.M = s->B * hc * wc;
       c.sy = c.sx = 1; c.oys = c.oxs = 2; c.oy0 = py; c.ox0 = px;
       pack_taps(c, n, oy, ox, wtp);
-      dispatch_igemm(c, st);
+      if (int e = dispatch_igemm(c, st)) return e;
       HRSEG_LAUNCH_CHECK("igemm_conv(dgrad s2)");
     }
   return 0;
