@@ -71,6 +71,8 @@ int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
 /* tuning/debug: override the implicit-GEMM tile plan (0 = automatic) -- pixel tiles per wave
  * (1,2,4), 16-channel K chunks per stage (1-3), LDS buffers (1,2), split-K factor */
 int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);
+/* same for the weight-gradient kernel: pixels per LDS stage (64,128), LDS buffers, target grid size */
+int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks);
 /* wt[ci][t][co] = w[co][t][ci] */
 int hrseg_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin,
                            hrseg_stream_t stream);

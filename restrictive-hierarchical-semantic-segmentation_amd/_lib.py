@@ -84,6 +84,14 @@ _lib.hrseg_debug_set_conv_tune.restype = _i
 _lib.hrseg_debug_set_conv_tune.argtypes = [_i, _i, _i, _i]
 
 
+_lib.hrseg_debug_set_wgrad_tune.restype = _i
+_lib.hrseg_debug_set_wgrad_tune.argtypes = [_i, _i, _i]
+
+
+def set_wgrad_tune(pix=0, db=0, target_blocks=0):
+    _lib.hrseg_debug_set_wgrad_tune(pix, db, target_blocks)
+
+
 def set_conv_tune(wtm=0, kc=0, db=0, ksplit=0):
     """tuning/debug override of the implicit-GEMM tile plan (0 = automatic)"""
     _lib.hrseg_debug_set_conv_tune(wtm, kc, db, ksplit)

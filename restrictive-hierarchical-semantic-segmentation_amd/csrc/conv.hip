@@ -390,25 +390,35 @@ struct WgradArgs {
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int M;            // B*Ho*Wo
   int ks, stride, T;
-  int pix_per_block;  // multiple of 64
-  unsigned long long div_hw, div_w;  // ceil(2^40/(Ho*Wo)), ceil(2^40/Wo)
+  int pix_per_block;  // multiple of the stage size
+  float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
 };
 
-__device__ __forceinline__ int fast_div(int n, unsigned long long magic) {
-  return (int)(((unsigned long long)(unsigned)n * magic) >> 40);
+// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction)
+__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
 }
 
-template <int TN, int TK>
+// Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
+// the stage's pixels (the MFMA k dimension), so each wave accumulates the full TN x TK tile set and
+// the block reduces across waves through LDS before the atomic add.
+// Staging: thread (r = tid>>2, q = tid&3) owns pixel rows r, r+64 and the 16-byte slot q of every
+// 16-channel chunk, so the pixel -> (b,oy,ox) decode is done once per row per stage.
+template <int TN, int TK, int PIX, int DB>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);  // row strides with (stride % 32) == 16
   constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
-  constexpr int STAGE = 64 * (SA + SB);
+  constexpr int ROWS = PIX / 64;                     // rows per thread
+  constexpr int STAGE = PIX * (SA + SB);
   constexpr int RED = 4 * TN * TK * 256;
-  constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  constexpr int LDS_FLOATS = (DB * STAGE > RED) ? DB * STAGE : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // blockIdx.y -> (tap, cout tile, cin tile)
   const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
   int id = blockIdx.y;
   const int kt = id % nkt;
@@ -421,51 +431,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
   const int lo = blockIdx.x * p.pix_per_block;
   const int hi = min(lo + p.pix_per_block, p.M);
-  const int nstages = (hi - lo + 63) >> 6;
+  const int nstages = (hi - lo + PIX - 1) / PIX;
+  const int q = tid & 3, r0 = tid >> 2;
 
-  f32x4 ra[TN], rb[TK];
+  f32x4 ra[ROWS][TN], rb[ROWS][TK];
   auto stage_load = [&](int s) {
-    const int base = lo + (s << 6);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int f = tid + 256 * i;  // float4 index in [64][4*TN]
-      const int r = f / (4 * TN), c4 = f - r * (4 * TN);
-      const int m = base + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < hi) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + n0 + 4 * c4);
-      ra[i] = v;
-    }
+    for (int i = 0; i < ROWS; ++i) {
+      const int m = lo + s * PIX + r0 + 64 * i;
+      const bool ok = m < hi;
+      const float* dyp = p.dy + (size_t)(ok ? m : 0) * p.lddy + n0 + 4 * q;
 #pragma unroll
-    for (int i = 0; i < TK; ++i) {
-      const int f = tid + 256 * i;
-      const int r = f / (4 * TK), c4 = f - r * (4 * TK);
-      const int m = base + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < hi) {
-        const int b = fast_div(m, p.div_hw);
-        const int rem = m - b * (p.Ho * p.Wo);
-        const int oy = fast_div(rem, p.div_w), ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
-        if ((iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi))
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.ldx + k0 + 4 * c4);
+      for (int j = 0; j < TN; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(dyp + 16 * j);
+        ra[i][j] = v;
       }
-      rb[i] = v;
+      const int b = fdiv(m, p.Ho * p.Wo, p.rcp_hw);
+      const int rem = m - b * (p.Ho * p.Wo);
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
+      const bool okx = ok & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      const float* xp = p.x + (size_t)(okx ? ((b * p.Hi + iy) * p.Wi + ix) : 0) * p.ldx + k0 + 4 * q;
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (okx) v = *reinterpret_cast<const f32x4*>(xp + 16 * j);
+        rb[i][j] = v;
+      }
     }
   };
   auto stage_store = [&](int buf) {
     float* a = lds + buf * STAGE;
-    float* b = a + 64 * SA;
+    float* b = a + PIX * SA;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int f = tid + 256 * i;
-      const int r = f / (4 * TN), c4 = f - r * (4 * TN);
-      *reinterpret_cast<f32x4*>(a + r * SA + 4 * c4) = ra[i];
-    }
+    for (int i = 0; i < ROWS; ++i) {
+      const int r = r0 + 64 * i;
 #pragma unroll
-    for (int i = 0; i < TK; ++i) {
-      const int f = tid + 256 * i;
-      const int r = f / (4 * TK), c4 = f - r * (4 * TK);
-      *reinterpret_cast<f32x4*>(b + r * SB + 4 * c4) = rb[i];
+      for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(a + r * SA + 16 * j + 4 * q) = ra[i][j];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(b + r * SB + 16 * j + 4 * q) = rb[i][j];
     }
   };
 
@@ -483,11 +488,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   for (int s = 0; s < nstages; ++s) {
     const bool more = s + 1 < nstages;
     if (more) stage_load(s + 1);
-    const float* a = lds + (s & 1) * STAGE;
-    const float* b = a + 64 * SA;
+    const float* a = lds + ((DB == 2) ? (s & 1) : 0) * STAGE;
+    const float* b = a + PIX * SA;
 #pragma unroll
-    for (int ks4 = 0; ks4 < 4; ++ks4) {
-      const int row = wave * 16 + ks4 * 4 + (lane >> 4);
+    for (int ks4 = 0; ks4 < PIX / 16; ++ks4) {
+      const int row = wave * (PIX / 4) + ks4 * 4 + (lane >> 4);
       float af[TN], bf[TK];
 #pragma unroll
       for (int n = 0; n < TN; ++n) af[n] = a[row * SA + 16 * n + (lane & 15)];
@@ -499,7 +504,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         for (int k = 0; k < TK; ++k)
           acc[n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n], bf[k], acc[n][k], 0, 0, 0);
     }
-    if (more) stage_store((s + 1) & 1);
+    if (DB == 1) __syncthreads();
+    if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
     __syncthreads();
   }
 
@@ -525,17 +531,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-template <int TN, int TK>
-static int launch_wgrad(WgradArgs a, hipStream_t st) {
+static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
+extern "C" int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks) {
+  g_tune_wg_pix = pix; g_tune_wg_db = db; g_tune_wg_blocks = target_blocks;
+  return 0;
+}
+
+template <int TN, int TK, int PIX, int DB>
+static void launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
   const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
-  // aim for ~1024 blocks; each block at least 4 stages (256 pixels)
-  int ksplit = 1024 / tiles;
+  int ksplit = target_blocks / tiles;
   if (ksplit < 1) ksplit = 1;
-  int ppb = ceil_div(ceil_div(a.M, ksplit), 64) * 64;
-  if (ppb < 256) ppb = 256;
+  int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
+  if (ppb < 4 * PIX) ppb = 4 * PIX;
   a.pix_per_block = ppb;
   const int gx = ceil_div(a.M, ppb);
-  hipLaunchKernelGGL((wgrad_kernel<TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((wgrad_kernel<TN, TK, PIX, DB>), dim3(gx, tiles), dim3(256), 0, st, a);
+}
+
+template <int TN, int TK>
+static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  // measured (tools/wgrad_sweep.py): 64-pixel stages, single LDS buffer; grid of ~7 blocks per
+  // output tile set, between 2 and 16 blocks per CU
+  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
+  int pix = 64, db = 1, target = 7 * tiles;
+  if (target < 512) target = 512;
+  if (target > 4096) target = 4096;
+  if (g_tune_wg_pix) pix = g_tune_wg_pix;
+  if (g_tune_wg_db) db = g_tune_wg_db;
+  if (g_tune_wg_blocks) target = g_tune_wg_blocks;
+  if (pix == 64 && db == 1) launch_wgrad_cfg<TN, TK, 64, 1>(a, target, st);
+  else if (pix == 64) launch_wgrad_cfg<TN, TK, 64, 2>(a, target, st);
+  else if (db == 1) launch_wgrad_cfg<TN, TK, 128, 1>(a, target, st);
+  else launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
   return 0;
 }
 
@@ -568,8 +596,8 @@ static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(ho == s->Ho && wo == s->Wo, "%s: output %dx%d does not match input %dx%d k%d s%d (expect %dx%d)",
                   who, s->Ho, s->Wo, s->Hi, s->Wi, s->ksize, s->stride, ho, wo);
   HRSEG_CHECK_ARG(s->ldx >= s->Cin && s->ldy >= s->Cout, "%s: ld smaller than channel count", who);
-  HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 30) && (long)s->B * s->Ho * s->Wo < (1L << 21) * 4,
-                  "%s: tensor too large for 32-bit pixel indexing", who);
+  HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 24) && (long)s->B * s->Ho * s->Wo < (1L << 24),
+                  "%s: more than 2^24 pixels per tensor is not supported (exact float index division)", who);
   return 0;
 }
 
@@ -686,9 +714,8 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   a.x = x; a.dy = dy; a.dw = dw; a.ldx = s->ldx; a.lddy = s->ldy;
   a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.Cin = s->Cin; a.Ho = s->Ho; a.Wo = s->Wo; a.Cout = s->Cout;
   a.M = s->B * s->Ho * s->Wo; a.ks = s->ksize; a.stride = s->stride; a.T = T;
-  const unsigned long long one = 1ULL << 40;
-  a.div_hw = (one + (unsigned long long)(s->Ho * s->Wo) - 1) / (unsigned long long)(s->Ho * s->Wo);
-  a.div_w = (one + (unsigned long long)s->Wo - 1) / (unsigned long long)s->Wo;
+  a.rcp_hw = 1.0f / (float)(s->Ho * s->Wo);
+  a.rcp_w = 1.0f / (float)s->Wo;
   const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
   const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
 #define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { launch_wgrad<TN_, TK_>(a, st); }
