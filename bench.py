@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--size", type=int, default=620)
     ap.add_argument("--flat", action="store_true", help="non-hierarchical (model_type 0)")
     ap.add_argument("--tree", default="class_tree_tl.json")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying "
+                                                             "the captured hipGraph (always the case for N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     return ap.parse_args()
@@ -163,7 +165,13 @@ def main():
     model.train()
     level_loss = []
 
+    graphed = None
+    if world == 1 and not args.no_graph:
+        graphed = T.GraphedTrainStep(model, opt, loss_fns, ns, tree, x, t, warmup=1)
+
     def step():
+        if graphed is not None:
+            return graphed(x, t)
         return T.train_step(model, opt, x, t, loss_fns, ns, tree, level_loss)
 
     def log(msg):
@@ -206,7 +214,8 @@ def main():
                                    "CE+Dice+consistency, bwd, grad all-reduce, AdamW)" % (
                                        "HRNet-W48" if args.model == "hrnet" else "UNet",
                                        "hierarchical" if hier else "flat", args.tree, args.size, args.size, args.batch),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": final_loss},
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "launch": "hipGraph replay" if graphed is not None else "eager"},
         }
         if gf is not None and args.size == 620:
             tf = ips * gf / 1e3

@@ -215,6 +215,11 @@ int hrseg_predict_metrics(const float* z, const float* t, float* onehot, long lo
 int hrseg_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                 float beta2, float eps, float weight_decay, float bc1, float bc2, float gscale,
                 hrseg_stream_t stream);
+/* same update with every scalar in DEVICE memory (hipGraph-replayable): hyper = {lr, beta1, beta2,
+ * eps, weight_decay, grad_scale}; state = {step, 1-beta1^step, 1/sqrt(1-beta2^step)} is advanced by
+ * one step per call. */
+int hrseg_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper,
+                    float* state, hrseg_stream_t stream);
 int hrseg_fill(float* p, float v, long n, hrseg_stream_t stream);
 
 #ifdef __cplusplus

@@ -118,7 +118,7 @@ class _Run:
                     if dp is None:
                         continue
                     if dz is not None and not own:
-                        dz, own = dz.clone(), True      # never write into autograd's tensor
+                        dz, own = ops.clone(dz), True  # never write into autograd's tensor
                     if L == 0:
                         dz = ops.sigmoid_bwd(dp, z, dz=dz, accumulate=dz is not None)
                         own = True
@@ -126,7 +126,7 @@ class _Run:
                         gp, gs = lv["groups"]
                         prev = dp_full[L - 1]
                         if prev is not None and not dp_own[L - 1]:
-                            prev = prev.contiguous().clone()
+                            prev = ops.clone(prev)
                         dz, prev = ops.compose_bwd(dp, z, self.probs[L - 1], gp, gs, dz=dz,
                                                    dz_accumulate=dz is not None, dpprev=prev,
                                                    dpprev_accumulate=prev is not None)
@@ -209,7 +209,7 @@ class _EngineModel(nn.Module):
             else:
                 g = self.child_groups[L - 1]
                 if len(g) == 0:
-                    p = torch.zeros_like(z)
+                    p = ops.zeros(z.shape, torch.float32, z.device)
                 else:
                     gp = [self.levels[L - 1].index(pname) for pname, _ in g]
                     gs = [len(ch) for _, ch in g]
@@ -247,7 +247,7 @@ class _EngineModel(nn.Module):
             dzl = ops.logits_up_bwd(dz, lv["low"][0], lv["low"][1], self.align_corners)
         else:
             dzl = ops.nchw_to_nhwc(dz)
-        dgb = torch.zeros_like(lv["gb"]) if film is not None else None
+        dgb = ops.zeros(lv["gb"].shape, torch.float32, lv["gb"].device) if film is not None else None
         feats.grad = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
                                   head.bias._hr_gstore, dgb, cout=head.out_channels)
         if film is None:

@@ -498,6 +498,44 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// Graph-replayable AdamW: step count and hyper-parameters live in device memory, so a captured
+// launch picks up the next step's bias correction and a scheduler's new lr on every replay.
+// hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale}; state = {step, bc1, 1/sqrt(bc2)}
+__global__ void adam_tick_kernel(float* state, const float* hyper) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double step = (double)state[0] + 1.0;
+    state[0] = (float)step;
+    state[1] = (float)(1.0 - pow((double)hyper[1], step));
+    state[2] = (float)(1.0 / sqrt(1.0 - pow((double)hyper[2], step)));
+  }
+}
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n4, long n,
+                                                        const float* __restrict__ hyper,
+                                                        const float* __restrict__ state) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5];
+  const float step = lr / state[1], rsqrt_bc2 = state[2];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = ld4(p + 4 * i), gg = ld4(g + 4 * i) * gscale, mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+    pp = pp * (1.f - lr * wd);
+    mm = mm + (gg - mm) * (1.f - b1);
+    vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pp[j] -= step * mm[j] / (sqrtf(vv[j]) * rsqrt_bc2 + eps);
+    st4(p + 4 * i, pp);
+    st4(m + 4 * i, mm);
+    st4(v + 4 * i, vv);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) {
+    const long i = 4 * n4 + threadIdx.x;
+    float pp = p[i] * (1.f - lr * wd), gg = g[i] * gscale;
+    const float mm = m[i] + (gg - m[i]) * (1.f - b1), vv = v[i] * b2 + gg * gg * (1.f - b2);
+    p[i] = pp - step * mm / (sqrtf(vv) * rsqrt_bc2 + eps);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
 // =========================================================================== C ABI
 static long chunk_size(long npix, int nchunks) { return (npix + nchunks - 1) / nchunks; }
 
@@ -701,5 +739,23 @@ extern "C" int hrseg_adamw(float* p, const float* g, float* m, float* v, long n,
   hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1,
                      beta2, eps, weight_decay, bc1, 1.0f / sqrtf(bc2), gscale);
   HRSEG_LAUNCH_CHECK("adamw");
+  return 0;
+}
+
+extern "C" int hrseg_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float* state,
+                               hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(p && g && m && v && hyper && state && n > 0, "hrseg_adamw_dev: bad arguments");
+  HRSEG_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                      ((uintptr_t)v % 16 == 0),
+                  "hrseg_adamw_dev: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, hyper);
+  HRSEG_LAUNCH_CHECK("adam_tick");
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3((int)blocks), dim3(256), 0, st, p, g, m, v, n4, n, hyper, state);
+  HRSEG_LAUNCH_CHECK("adamw_dev");
   return 0;
 }

@@ -242,6 +242,16 @@ extern "C" int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit) {
   return 0;
 }
 
+// zero fill as a KERNEL node (not hipMemsetAsync): keeps a captured hipGraph a pure kernel chain
+__global__ void zero_f32_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static void zero_f32(float* p, size_t n, hipStream_t st) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+}
+
 struct IgemmPlan { int wtm, wtn, kc, db, ksplit; };
 
 static IgemmPlan plan_igemm(const IgemmArgs& a) {
@@ -278,9 +288,7 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
 
 static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
   IgemmPlan pl = plan_igemm(a);
-  if (pl.ksplit > 1 && !a.accumulate) {
-    if (hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.B * a.Hy * a.Wy * a.N, st) != hipSuccess) pl.ksplit = 1;
-  }
+  if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
 #define IG4(M_, N_, K_, D_) \
   if (pl.wtm == M_ && pl.wtn == N_ && pl.kc == K_ && pl.db == D_) { launch_igemm<M_, N_, K_, D_>(a, pl.ksplit, st); return 0; }
 #define IG3(M_, N_, K_) IG4(M_, N_, K_, 1) IG4(M_, N_, K_, 2)

@@ -414,6 +414,10 @@ __global__ void compose_bwd_kernel(const float* __restrict__ dp, long sb, long s
   }
 }
 
+__global__ void zero_f64_kernel(double* p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
+}
+
 // --------------------------------------------------------------------------- loss
 // per (b,c): {n, sum t logp, sum p t, sum p, sum t} over pixels with t != -1
 template <int CT>
@@ -806,7 +810,7 @@ extern "C" int hrseg_loss_partials(const float* z, const float* t, double* parti
                                    hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(z && t && partial && B > 0 && C > 0 && C <= MAXC && hw > 0, "hrseg_loss_partials: bad arguments (C=%d)", C);
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(partial, 0, sizeof(double) * (size_t)B * C * 5, st);
+  hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(256), 0, st, partial, B * C * 5);   // kernel node, not memset
   long chunks = 1024 / B;
   if (chunks < 1) chunks = 1;
   long ppb = (hw + chunks - 1) / chunks;

@@ -89,7 +89,7 @@ class FlatParams:
     def prepare_backward(self):
         """zero_grad(set_to_none=True) detaches the views: the flat gradient then restarts from zero."""
         if self._first.grad is None and not self.grads_fresh:
-            self.grad.zero_()
+            ops.fill(self.grad, 0.0)
         self.grads_fresh = False
 
 

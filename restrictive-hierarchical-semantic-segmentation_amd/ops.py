@@ -36,6 +36,28 @@ def _npix(t):
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+def zeros(shape, dtype, device):
+    """zero-filled tensor through the library's fill KERNEL (torch.zeros issues a memset, which a
+    captured hipGraph replays out of order on this stack -- see tools/graph_bisect.py)"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    flat = t.view(-1).view(torch.float32)      # int64/float64 zeros are all-zero bits too
+    call("hrseg_fill", ptr(flat), 0.0, flat.numel())
+    return t
+
+
+def clone(t):
+    """device copy through the library's copy KERNEL (clone() of a contiguous tensor is a D2D memcpy
+    node under graph capture; kept out of captured graphs like the memsets)"""
+    t = t.contiguous()
+    out = torch.empty_like(t)
+    n = t.numel()
+    if t.dtype == torch.float32 and n % 4 == 0 and n > 0:
+        call("hrseg_copy", ptr(t), 4, ptr(out), 4, 0, n // 4, 4)
+    else:
+        out.copy_(t)
+    return out
+
+
 def empty_nhwc(B, H, W, Cn, like):
     return torch.empty((B, H, W, Cn), dtype=torch.float32, device=like.device)
 
@@ -347,7 +369,7 @@ def consistency_sums(p, pprev, group_parent, group_size):
     """-> [ngroups] float64 sums of |sum_children P - P_parent| over batch and pixels"""
     p, pprev = _c(p), _c(pprev)
     B, Cn, H, W = p.shape
-    out = torch.zeros(len(group_parent), dtype=torch.float64, device=p.device)
+    out = zeros((len(group_parent),), torch.float64, p.device)
     call("hrseg_consistency", ptr(p), ptr(pprev), ptr(out), B, Cn, pprev.shape[1], H * W, len(group_parent),
          _lib.int_array(group_parent), _lib.int_array(group_size))
     return out
@@ -359,7 +381,7 @@ def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):
     B, Cn, H, W = z.shape
     K = Cn + (1 if child else 0)
     onehot = torch.empty_like(z) if (want_onehot and mask_pred) else None
-    cm = torch.zeros((K, K), dtype=torch.int64, device=z.device)
+    cm = zeros((K, K), torch.int64, z.device)
     call("hrseg_predict_metrics", ptr(z), ptr(t), ptr(onehot), ptr(cm), B, Cn, H * W, int(child), int(mask_pred))
     return onehot, cm
 
@@ -369,3 +391,8 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     bc2 = 1.0 - beta2 ** step
     call("hrseg_adamw", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
          float(wd), float(bc1), float(bc2), float(gscale))
+
+
+def adamw_dev(p, g, m, v, hyper, state):
+    """graph-replayable AdamW step: hyper/state are device tensors (see hrseg.h)"""
+    call("hrseg_adamw_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), ptr(state))

@@ -38,8 +38,22 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._m = self._v = None
+        self._hyper = self._state = self._hyper_host = None
         self._step = 0
         self.grad_scale = 1.0
+
+    def _sync_hyper(self, device):
+        """device copies of the scalars (read by the kernel, so a captured graph sees updates)"""
+        g = self.param_groups[0]
+        host = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                float(g["weight_decay"]), float(self.grad_scale))
+        if self._hyper is None or self._hyper.device != device:
+            self._hyper = torch.tensor(host, dtype=torch.float32, device=device)
+            self._state = torch.tensor([float(self._step), 0.0, 0.0], dtype=torch.float32, device=device)
+            self._hyper_host = host
+        elif host != self._hyper_host:
+            self._hyper.copy_(torch.tensor(host, dtype=torch.float32))
+            self._hyper_host = host
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,10 +61,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None or self._m.numel() != flat.numel or self._m.device != flat.data.device:
             self._m = torch.zeros_like(flat.data)
             self._v = torch.zeros_like(flat.data)
-        g = self.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_hyper(flat.data.device)
         self._step += 1
-        ops.adamw(flat.data, flat.grad, self._m, self._v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                  g["weight_decay"], self._step, self.grad_scale)
+        ops.adamw_dev(flat.data, flat.grad, self._m, self._v, self._hyper, self._state)
 
     def zero_grad(self, set_to_none=True):
         flat = self.model._flat
@@ -62,12 +76,15 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.grad = None
 
     def state_dict(self):
+        if self._state is not None:
+            self._step = int(self._state[0].item())      # graph replays advance the device counter
         return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups":
                 [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd):
         self._step, self._m, self._v = sd["step"], sd["exp_avg"], sd["exp_avg_sq"]
         self.param_groups[0].update(sd["param_groups"][0])
+        self._hyper = None                                # rebuilt (with the loaded step) on the next step
 
 
 # ----------------------------------------------------------------------------- metrics
@@ -190,6 +207,42 @@ def train_step(model, optimizer, data, target, lossFuncts, args, class_tree, lev
     loss.backward()
     optimizer.step()
     return loss.detach(), cms
+
+
+class GraphedTrainStep:
+    """One train step (zero_grad, forward of the L passes, prediction prep + confusion counts,
+    loss, backward, AdamW) captured ONCE into a hipGraph and replayed per batch.
+
+    A hier HRNet-W48 step is ~7,000 short kernels; issued one by one from Python the host becomes
+    the limit (~15 us per launch).  The captured graph replays them with no host work.  Inputs are
+    copied into static buffers; outputs (loss, per-level confusion matrices, accumulated level
+    losses) are static device tensors.  `warmup` eager steps (real optimizer steps on the example
+    batch) run first so every lazily built buffer exists before capture.  Not used with a
+    gradient hook (multi-GPU): collectives stay outside the graph, see `train_step`."""
+
+    def __init__(self, model, optimizer, lossFuncts, args, class_tree, data, target, warmup=2, epoch_num=1):
+        self.model, self.optimizer = model, optimizer
+        self.x, self.t = data.clone(), target.clone()
+        level_loss = []
+        for _ in range(max(1, warmup)):
+            train_step(model, optimizer, self.x, self.t, lossFuncts, args, class_tree, level_loss, epoch_num)
+        torch.cuda.synchronize()
+        self.level_loss = torch.zeros(len(level_loss), device=data.device)
+        optimizer._sync_hyper(data.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            ll = []
+            self.loss, self.cms = train_step(model, optimizer, self.x, self.t, lossFuncts, args, class_tree, ll,
+                                             epoch_num)
+            self.level_loss.add_(torch.stack([torch.as_tensor(v, device=data.device).float().reshape(()) for v in ll]))
+        torch.cuda.synchronize()
+
+    def __call__(self, data, target):
+        self.x.copy_(data, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self.optimizer._sync_hyper(self.x.device)
+        self.graph.replay()
+        return self.loss, self.cms
 
 
 def _unwrap(model):
