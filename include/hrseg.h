@@ -68,6 +68,17 @@ int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int accumulate
  * running gradient, zeroed by the caller at the start of a step). */
 int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
                      const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* Grouped forms: n independent convolutions (the parallel HRNet branches, models.py:524-525) in
+ * ONE launch when they can share a kernel instance (channel counts all multiples of 48 or all of
+ * 64, stride 1 for dgrad), else n separate launches.  Pointer arrays are HOST arrays. */
+int hrseg_conv_fwd_group(int n, const float* const* x, const float* const* w,
+                         const float* const* bias, float* const* y,
+                         const hrseg_conv_shape_t* shapes, hrseg_stream_t stream);
+int hrseg_conv_dgrad_group(int n, const float* const* dy, const float* const* wt, float* const* dx,
+                           const int* accumulate, const hrseg_conv_shape_t* shapes,
+                           hrseg_stream_t stream);
+int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy, float* const* dw,
+                           const hrseg_conv_shape_t* shapes, hrseg_stream_t stream);
 /* tuning/debug: override the implicit-GEMM tile plan (0 = automatic) -- pixel tiles per wave
  * (1,2,4), 16-channel K chunks per stage (1-3), LDS buffers (1,2), split-K factor */
 int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);

@@ -477,10 +477,26 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _run_branches(self, rec, xs):
+        """The branches are independent chains of equally many BasicBlocks: walk them in lockstep
+        so that step k of every branch goes out as one grouped launch (engine.conv_bn_group)."""
+        nb = self.num_branches
+        depth = len(self.branches[0])
+        lockstep = all(len(br) == depth and all(isinstance(blk, BasicBlock) and blk.downsample is None for blk in br)
+                       for br in self.branches)
+        if not lockstep:
+            return [_run_seq(rec, self.branches[b], xs[b]) for b in range(nb)]
+        xs = list(xs)
+        for kblk in range(depth):
+            blks = [self.branches[b][kblk] for b in range(nb)]
+            ys = rec.conv_bn_group([(xs[b], blks[b].conv1, blks[b].bn1, None) for b in range(nb)], relu=True)
+            xs = rec.conv_bn_group([(ys[b], blks[b].conv2, blks[b].bn2, xs[b]) for b in range(nb)], relu=True)
+        return xs
+
     def run(self, rec, xs):
         if self.num_branches == 1:
             return [_run_seq(rec, self.branches[0], xs[0])]
-        xs = [_run_seq(rec, self.branches[b], xs[b]) for b in range(self.num_branches)]
+        xs = self._run_branches(rec, xs)
         outs = []
         for i, row in enumerate(self.fuse_layers):
             terms = []

@@ -39,6 +39,9 @@ PROTOTYPES = {
     "hrseg_conv_fwd": [_p, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_conv_dgrad": [_p, _p, _p, _i, C.POINTER(ConvShape), _p],
     "hrseg_conv_wgrad": [_p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_conv_fwd_group": [_i, _p, _p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_conv_dgrad_group": [_i, _p, _p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_conv_wgrad_group": [_i, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_weight_transpose": [_p, _p, _i, _i, _i, _p],
     "hrseg_bn_stats": [_p, _i, _l, _i, _p, _i, _p],
     "hrseg_bn_finalize": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p],
@@ -128,6 +131,11 @@ def call(name, *args):
     rc = _fn[name](*args, stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def ptr_array(tensors):
+    """host array of device pointers (None -> NULL)"""
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def int_array(values):

@@ -47,25 +47,24 @@ __device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ ((-(r
 // half the LDS, so more blocks per CU).  gridDim.y > 1 = split-K over the stage list: partial
 // sums are added with fp32 atomics.
 template <int WTM, int WTN, int KC, int DB>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const int bid, const int nblk,
+                                           const int ks_idx, const int ks_n) {
   constexpr int BM = 64 * WTM;  // pixels per block
   constexpr int BN = 16 * WTN;  // channels per block
   constexpr int A_ROWS = BM / 64;
   constexpr int B_F4 = BN * 4 * KC;
   constexpr int B_LOADS = (B_F4 + 255) / 256;
   constexpr int STAGE = (BM + BN) * 16 * KC;  // floats per LDS buffer
-  __shared__ __attribute__((aligned(16))) float lds[DB * STAGE];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = p.N / BN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = xcd_remap(bid, nblk);
   const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
 
   // stage range of this block (split-K)
   const int kchunks = p.K / (16 * KC);
   const int nstages_all = p.ntaps * kchunks;
-  const int per = (nstages_all + gridDim.y - 1) / gridDim.y;
-  const int s_lo = blockIdx.y * per;
+  const int per = (nstages_all + ks_n - 1) / ks_n;
+  const int s_lo = ks_idx * per;
   const int s_hi = min(s_lo + per, nstages_all);
   const int nstages = s_hi - s_lo;
 
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
 
   // epilogue: lane holds channels n0+16n+4g..+3 of pixel row (lane&15)
   const int g = lane >> 4;
-  const bool split = gridDim.y > 1;
+  const bool split = ks_n > 1;
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
     const int row = m0 + wave * 16 * WTM + 16 * m + (lane & 15);
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
     for (int n = 0; n < WTN; ++n) {
       const int ch = n0 + 16 * n + 4 * g;
       f32x4 v = acc[n][m];
-      if (p.bias && blockIdx.y == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
       if (split) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
@@ -229,10 +228,40 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
 }
 
 template <int WTM, int WTN, int KC, int DB>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[DB * (64 * WTM + 16 * WTN) * 16 * KC];
+  igemm_body<WTM, WTN, KC, DB>(p, lds, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+}
+
+// Several independent convolutions (the parallel HRNet branches) in ONE grid: block ranges
+// [blk_end[g-1], blk_end[g]) belong to problem g, each with its own tile count and split-K factor.
+#define MAXG 4
+struct IgemmGroup {
+  int n;
+  int blk_end[MAXG];
+  int tiles[MAXG];   // m-tiles * n-tiles of problem g (its blocks = tiles * ksplit)
+  int ksplit[MAXG];
+  IgemmArgs a[MAXG];
+};
+template <int WTM, int WTN, int KC, int DB>
+__global__ __launch_bounds__(256) void igemm_group_kernel(IgemmGroup grp) {
+  __shared__ __attribute__((aligned(16))) float lds[DB * (64 * WTM + 16 * WTN) * 16 * KC];
+  int g = 0;
+  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
+  const int local = blockIdx.x - (g ? grp.blk_end[g - 1] : 0);
+  const int tiles = grp.tiles[g];
+  igemm_body<WTM, WTN, KC, DB>(grp.a[g], lds, local % tiles, tiles, local / tiles, grp.ksplit[g]);
+}
+
+template <int WTM, int WTN, int KC, int DB>
 static void launch_igemm(const IgemmArgs& a, int ksplit, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 16 * WTN;
   const int grid = ceil_div(a.M, BM) * (a.N / BN);
   hipLaunchKernelGGL((igemm_conv_kernel<WTM, WTN, KC, DB>), dim3(grid, ksplit), dim3(256), 0, st, a);
+}
+template <int WTM, int WTN, int KC, int DB>
+static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
+  hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
 }
 
 // debug/tuning override (0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
@@ -301,6 +330,56 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
 #undef IG4
   hrseg_set_error("igemm: no kernel for plan wtm=%d wtn=%d kc=%d db=%d", pl.wtm, pl.wtn, pl.kc, pl.db);
   return HRSEG_ERR_UNSUPPORTED;
+}
+
+// group dispatch: one common plan (64-pixel tiles, widest K stage, single LDS buffer); problems whose
+// channel tiling differs from the first one's, or that need a zero-fill they cannot get, make the
+// caller fall back to per-problem launches (return 1).
+static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
+  if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
+  const int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
+  const int kc = (a[0].K % 48 == 0) ? 3 : (a[0].K % 32 == 0) ? 2 : 1;
+  if (!wtn) return 1;
+  IgemmGroup g;
+  g.n = n;
+  for (int i = 0; i < n; ++i)
+    if (a[i].N % (16 * wtn) || a[i].K % (16 * kc)) return 1;
+  // per-problem split-K, then order the problems by stages per block, longest first: the blocks
+  // that run longest must not be the ones dispatched last (the grid's tail)
+  int tiles[MAXG], ks[MAXG], work[MAXG], order[MAXG];
+  for (int i = 0; i < n; ++i) {
+    tiles[i] = ceil_div(a[i].M, 64) * (a[i].N / (16 * wtn));
+    const int nstages = a[i].ntaps * (a[i].K / (16 * kc));
+    ks[i] = 1;
+    const bool can_split = a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1);
+    if (can_split && tiles[i] < 512) {
+      ks[i] = ceil_div(512, tiles[i]);
+      if (ks[i] > nstages / 3) ks[i] = nstages / 3;
+      if (ks[i] < 1) ks[i] = 1;
+    }
+    if (ks[i] > 1 && !a[i].accumulate) zero_f32(a[i].y, (size_t)a[i].B * a[i].Hy * a[i].Wy * a[i].N, st);
+    work[i] = ceil_div(nstages, ks[i]);
+    order[i] = i;
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (work[order[j]] > work[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  int end = 0;
+  for (int o = 0; o < n; ++o) {
+    const int i = order[o];
+    g.tiles[o] = tiles[i];
+    g.ksplit[o] = ks[i];
+    end += tiles[i] * ks[i];
+    g.blk_end[o] = end;
+    g.a[o] = a[i];
+  }
+  if (wtn == 3 && kc == 3) launch_igemm_group<1, 3, 3, 1>(g, st);
+  else if (wtn == 3 && kc == 2) launch_igemm_group<1, 3, 2, 1>(g, st);
+  else if (wtn == 3) launch_igemm_group<1, 3, 1, 1>(g, st);
+  else if (kc == 3) launch_igemm_group<1, 4, 3, 1>(g, st);
+  else if (kc == 2) launch_igemm_group<1, 4, 2, 1>(g, st);
+  else launch_igemm_group<1, 4, 1, 1>(g, st);
+  return 0;
 }
 
 // --------------------------------------------------------------------------- direct conv, Cin <= 4
@@ -417,18 +496,13 @@ __device__ __forceinline__ int fdiv(int n, int d, float rcp) {
 // Staging: thread (r = tid>>2, q = tid&3) owns pixel rows r, r+64 and the 16-byte slot q of every
 // 16-channel chunk, so the pixel -> (b,oy,ox) decode is done once per row per stage.
 template <int TN, int TK, int PIX, int DB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const int bx, int id) {
   constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);  // row strides with (stride % 32) == 16
   constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
   constexpr int ROWS = PIX / 64;                     // rows per thread
   constexpr int STAGE = PIX * (SA + SB);
-  constexpr int RED = 4 * TN * TK * 256;
-  constexpr int LDS_FLOATS = (DB * STAGE > RED) ? DB * STAGE : RED;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
-  int id = blockIdx.y;
   const int kt = id % nkt;
   id /= nkt;
   const int ct = id % nct;
@@ -437,7 +511,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int pad = (p.ks - 1) / 2;
   const int kh = tap / p.ks - pad, kw = tap % p.ks - pad;
 
-  const int lo = blockIdx.x * p.pix_per_block;
+  const int lo = bx * p.pix_per_block;
   const int hi = min(lo + p.pix_per_block, p.M);
   const int nstages = (hi - lo + PIX - 1) / PIX;
   const int q = tid & 3, r0 = tid >> 2;
@@ -539,6 +613,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
+template <int TN, int TK, int PIX, int DB>
+struct WgradLds {
+  static constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16), SB = 16 * TK + ((TK % 2) ? 0 : 16);
+  static constexpr int STAGE = PIX * (SA + SB), RED = 4 * TN * TK * 256;
+  static constexpr int FLOATS = (DB * STAGE > RED) ? DB * STAGE : RED;
+};
+template <int TN, int TK, int PIX, int DB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradLds<TN, TK, PIX, DB>::FLOATS];
+  wgrad_body<TN, TK, PIX, DB>(p, lds, blockIdx.x, blockIdx.y);
+}
+struct WgradGroup {
+  int n;
+  int blk_end[MAXG];
+  int gx[MAXG];       // pixel-range blocks of problem g (its blocks = gx * tiles)
+  WgradArgs a[MAXG];
+};
+template <int TN, int TK, int PIX, int DB>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup grp) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradLds<TN, TK, PIX, DB>::FLOATS];
+  int g = 0;
+  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
+  const int local = blockIdx.x - (g ? grp.blk_end[g - 1] : 0);
+  const int gx = grp.gx[g];
+  wgrad_body<TN, TK, PIX, DB>(grp.a[g], lds, local % gx, local / gx);
+}
+
 static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
 extern "C" int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks) {
   g_tune_wg_pix = pix; g_tune_wg_db = db; g_tune_wg_blocks = target_blocks;
@@ -572,6 +673,43 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   else if (pix == 64) launch_wgrad_cfg<TN, TK, 64, 2>(a, target, st);
   else if (db == 1) launch_wgrad_cfg<TN, TK, 128, 1>(a, target, st);
   else launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
+  return 0;
+}
+
+static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
+  tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
+  int target = 7 * tiles;
+  if (target < 512) target = 512;
+  if (target > 4096) target = 4096;
+  int ksplit = target / tiles;
+  if (ksplit < 1) ksplit = 1;
+  int ppb = ceil_div(ceil_div(a.M, ksplit), pix) * pix;
+  if (ppb < 4 * pix) ppb = 4 * pix;
+  a.pix_per_block = ppb;
+  gx = ceil_div(a.M, ppb);
+}
+
+// returns 1 when the problems cannot share one kernel instance (caller falls back)
+static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
+  if (n < 2 || n > MAXG || g_tune_wg_pix || g_tune_wg_db || g_tune_wg_blocks) return 1;
+  const int tn = (a[0].Cout % 48 == 0) ? 3 : (a[0].Cout % 64 == 0) ? 4 : 0;
+  const int tk = (a[0].Cin % 48 == 0) ? 3 : (a[0].Cin % 64 == 0) ? 4 : 0;
+  if (!tn || !tk) return 1;
+  WgradGroup g;
+  g.n = n;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].Cout % (16 * tn) || a[i].Cin % (16 * tk)) return 1;
+    int gx, tiles;
+    plan_wgrad_blocks(a[i], tn, tk, 64, gx, tiles);
+    g.gx[i] = gx;
+    end += gx * tiles;
+    g.blk_end[i] = end;
+    g.a[i] = a[i];
+  }
+#define WGG(TN_, TK_) if (tn == TN_ && tk == TK_) hipLaunchKernelGGL((wgrad_group_kernel<TN_, TK_, 64, 1>), dim3(end), dim3(256), 0, st, g);
+  WGG(3, 3) WGG(3, 4) WGG(4, 3) WGG(4, 4)
+#undef WGG
   return 0;
 }
 
@@ -617,6 +755,118 @@ static void pack_taps(IgemmArgs& a, int n, const int* oy, const int* ox, const i
     a.offx_pk |= (unsigned long long)(ox[t] + 8) << (4 * t);
     a.wtap_pk |= (unsigned long long)wt[t] << (4 * t);
   }
+}
+
+static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const float* bias, float* y,
+                          const hrseg_conv_shape_t* s) {
+  a = IgemmArgs{};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldx = s->ldx; a.ldy = s->ldy;
+  a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.K = s->Cin;
+  a.Ho = s->Ho; a.Wo = s->Wo; a.N = s->Cout; a.M = s->B * s->Ho * s->Wo;
+  a.sy = a.sx = s->stride;
+  a.Hy = s->Ho; a.Wy = s->Wo; a.oys = a.oxs = 1; a.oy0 = a.ox0 = 0;
+  a.T = s->ksize * s->ksize; a.accumulate = 0;
+  int oy[9], ox[9], wt[9];
+  const int pad = (s->ksize - 1) / 2;
+  for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
+  pack_taps(a, a.T, oy, ox, wt);
+}
+
+// stride-1 data gradient as a forward-style gather over dy with the transposed weights
+static void fill_dgrad_s1_args(IgemmArgs& a, const float* dy, const float* wt, float* dx, int accumulate,
+                               const hrseg_conv_shape_t* s) {
+  a = IgemmArgs{};
+  a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx; a.ldx = s->ldy; a.ldy = s->ldx;
+  a.B = s->B; a.Hi = s->Ho; a.Wi = s->Wo; a.K = s->Cout;
+  a.N = s->Cin; a.T = s->ksize * s->ksize; a.accumulate = accumulate;
+  a.Hy = s->Hi; a.Wy = s->Wi;
+  a.Ho = s->Hi; a.Wo = s->Wi; a.M = s->B * s->Hi * s->Wi;
+  a.sy = a.sx = 1; a.oys = a.oxs = 1; a.oy0 = a.ox0 = 0;
+  const int ks = s->ksize, pad = (ks - 1) / 2;
+  int oy[9], ox[9], wtp[9];
+  for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
+  pack_taps(a, a.T, oy, ox, wtp);
+}
+
+static void fill_wgrad_args(WgradArgs& a, const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s) {
+  a = WgradArgs{};
+  a.x = x; a.dy = dy; a.dw = dw; a.ldx = s->ldx; a.lddy = s->ldy;
+  a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.Cin = s->Cin; a.Ho = s->Ho; a.Wo = s->Wo; a.Cout = s->Cout;
+  a.M = s->B * s->Ho * s->Wo; a.ks = s->ksize; a.stride = s->stride; a.T = s->ksize * s->ksize;
+  a.rcp_hw = 1.0f / (float)(s->Ho * s->Wo);
+  a.rcp_w = 1.0f / (float)s->Wo;
+}
+
+static bool mfma_shape(const hrseg_conv_shape_t* s) {
+  return s->Cin % 16 == 0 && s->Cout % 16 == 0 && s->ldx % 4 == 0 && s->ldy % 4 == 0;
+}
+
+// ---- grouped entry points: n independent problems, one launch when they can share a kernel
+extern "C" int hrseg_conv_fwd_group(int n, const float* const* x, const float* const* w, const float* const* bias,
+                                    float* const* y, const hrseg_conv_shape_t* shapes, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && x && w && y && shapes, "hrseg_conv_fwd_group: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = n <= MAXG;
+  for (int i = 0; i < n; ++i) {
+    if (int e = check_shape(&shapes[i], "hrseg_conv_fwd_group")) return e;
+    ok = ok && mfma_shape(&shapes[i]);
+  }
+  if (ok && n >= 2) {
+    IgemmArgs a[MAXG];
+    for (int i = 0; i < n; ++i) fill_fwd_args(a[i], x[i], w[i], bias ? bias[i] : nullptr, y[i], &shapes[i]);
+    if (dispatch_igemm_group(a, n, st) == 0) {
+      HRSEG_LAUNCH_CHECK("igemm_group(fwd)");
+      return 0;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    if (int e = hrseg_conv_fwd(x[i], w[i], bias ? bias[i] : nullptr, y[i], &shapes[i], stream)) return e;
+  return 0;
+}
+
+extern "C" int hrseg_conv_dgrad_group(int n, const float* const* dy, const float* const* wt, float* const* dx,
+                                      const int* accumulate, const hrseg_conv_shape_t* shapes,
+                                      hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && dy && wt && dx && accumulate && shapes, "hrseg_conv_dgrad_group: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = n <= MAXG;
+  for (int i = 0; i < n; ++i) {
+    if (int e = check_shape(&shapes[i], "hrseg_conv_dgrad_group")) return e;
+    ok = ok && mfma_shape(&shapes[i]) && shapes[i].stride == 1;
+  }
+  if (ok && n >= 2) {
+    IgemmArgs a[MAXG];
+    for (int i = 0; i < n; ++i) fill_dgrad_s1_args(a[i], dy[i], wt[i], dx[i], accumulate[i], &shapes[i]);
+    if (dispatch_igemm_group(a, n, st) == 0) {
+      HRSEG_LAUNCH_CHECK("igemm_group(dgrad)");
+      return 0;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    if (int e = hrseg_conv_dgrad(dy[i], wt[i], dx[i], accumulate[i], &shapes[i], stream)) return e;
+  return 0;
+}
+
+extern "C" int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy, float* const* dw,
+                                      const hrseg_conv_shape_t* shapes, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && x && dy && dw && shapes, "hrseg_conv_wgrad_group: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = n <= MAXG;
+  for (int i = 0; i < n; ++i) {
+    if (int e = check_shape(&shapes[i], "hrseg_conv_wgrad_group")) return e;
+    ok = ok && mfma_shape(&shapes[i]);
+  }
+  if (ok && n >= 2) {
+    WgradArgs a[MAXG];
+    for (int i = 0; i < n; ++i) fill_wgrad_args(a[i], x[i], dy[i], dw[i], &shapes[i]);
+    if (dispatch_wgrad_group(a, n, st) == 0) {
+      HRSEG_LAUNCH_CHECK("wgrad_group");
+      return 0;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    if (int e = hrseg_conv_wgrad(x[i], dy[i], dw[i], &shapes[i], stream)) return e;
+  return 0;
 }
 
 extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias, float* y,

@@ -171,6 +171,57 @@ class Recorder:
         self._push(bwd)
         return z
 
+    def conv_bn_group(self, items, relu):
+        """items: list of (x, conv, bn, residual-or-None) that are independent of each other (the
+        parallel HRNet branches): the convolutions, their weight gradients and their data gradients
+        each go out as ONE grouped launch."""
+        if len(items) == 1:
+            x, conv, bn, res = items[0]
+            return [self.conv_bn(x, conv, bn, relu, res)]
+        k, s = items[0][1].kernel_size[0], items[0][1].stride[0]
+        assert all(c.kernel_size[0] == k and c.stride[0] == s for _, c, _, _ in items)
+        xs = [it[0] for it in items]
+        ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
+                                [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
+                                [c.out_channels for _, c, _, _ in items])
+        zs, coefs = [], []
+        for (x, conv, bn, res), y in zip(items, ys):
+            if self.training:
+                coef = ops.bn_train_coef(y, bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked, bn.momentum, bn.eps)
+            else:
+                coef = ops.bn_eval_coef(bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var, bn.eps)
+            coefs.append(coef)
+            zs.append(Act(ops.bn_apply(y, coef, res.data if res is not None else None, relu)))
+        if not self.record:
+            return zs
+        eval_mode = not self.training
+
+        def bwd():
+            dys = []
+            for (x, conv, bn, res), y, z, coef in zip(items, ys, zs, coefs):
+                dz = z.grad
+                z.grad = None
+                dres, dres_acc = None, False
+                if res is not None and res.needs_grad:
+                    if res.grad is None:
+                        res.grad = torch.empty(res.data.shape, dtype=torch.float32, device=dz.device)
+                    else:
+                        dres_acc = True
+                    dres = res.grad
+                dys.append(ops.bn_bwd(dz, z.data, relu, y, coef, bn.weight._hr_gstore, bn.bias._hr_gstore, dres,
+                                      dres_acc, eval_mode, dy_out=dz))
+            ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
+            need = [i for i, x in enumerate(xs) if x.needs_grad]
+            if need:
+                outs = ops.conv_dgrad_group([dys[i] for i in need], [self._wt(items[i][1]) for i in need],
+                                            [xs[i].data.shape for i in need], k, s, [xs[i].grad for i in need],
+                                            [xs[i].grad is not None for i in need])
+                for i, o in zip(need, outs):
+                    xs[i].grad = o
+        self._push(bwd)
+        return zs
+
     # ------------------------------------------------------------------ pooling
     def maxpool2(self, x):
         y = Act(ops.maxpool2_fwd(x.data))

@@ -103,6 +103,43 @@ def conv_wgrad(x, dy, dw, k, s):
     call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
 
 
+def _shape_array(shapes):
+    return (ConvShape * len(shapes))(*shapes)
+
+
+def conv_fwd_group(xs, ws, biases, k, s, couts):
+    """n independent convolutions (same k, s) in one launch when the library can group them"""
+    outs, shapes = [], []
+    for x, co in zip(xs, couts):
+        B, Hi, Wi, Cin = x.shape
+        y = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), co, x)
+        outs.append(y)
+        shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s))
+    has_bias = any(b is not None for b in biases)
+    call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
+         _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
+    return outs
+
+
+def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate):
+    """outs[i] None -> allocated (accumulate ignored)"""
+    outs, acc, shapes = list(outs), list(accumulate), []
+    for i, (dy, xs) in enumerate(zip(dys, x_shapes)):
+        if outs[i] is None:
+            outs[i] = empty_nhwc(xs[0], xs[1], xs[2], xs[3], dy)
+            acc[i] = False
+        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s))
+    call("hrseg_conv_dgrad_group", len(dys), _lib.ptr_array(dys), _lib.ptr_array(wts), _lib.ptr_array(outs),
+         _lib.int_array([int(a) for a in acc]), _shape_array(shapes))
+    return outs
+
+
+def conv_wgrad_group(xs, dys, dws, k, s):
+    shapes = [_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s) for x, dy in zip(xs, dys)]
+    call("hrseg_conv_wgrad_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(dys), _lib.ptr_array(dws),
+         _shape_array(shapes))
+
+
 def weight_transpose(w_store, Cout, taps, Cin, out=None):
     if out is None:
         out = torch.empty(Cin * taps * Cout, dtype=torch.float32, device=w_store.device)

@@ -361,3 +361,29 @@ def test_adamw_matches_torch(ops):
         opt.step()
         ops.adamw(pd, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
     assert rel(pd, pr.data) < 1e-6
+
+
+def test_grouped_conv_matches_single_launches(ops):
+    """four independent convs (HRNet branch shapes) through the grouped entry points"""
+    g = torch.Generator().manual_seed(11)
+    chans, sizes = [48, 96, 192, 384], [33, 17, 9, 5]
+    xs = [torch.randn(2, h, h, c, generator=g).cuda() for c, h in zip(chans, sizes)]
+    ws = [(torch.randn(c, 9, c, generator=g) / (9 * c) ** 0.5).cuda() for c in chans]
+    ys = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans)
+    dys = [torch.randn(y.shape, generator=g).cuda() for y in ys]
+    wts = [ops.weight_transpose(w, c, 9, c) for w, c in zip(ws, chans)]
+    dws = [torch.zeros_like(w) for w in ws]
+    ops.conv_wgrad_group(xs, dys, dws, 3, 1)
+    seed = [torch.randn(x.shape, generator=g).cuda() for x in xs]
+    dxs = ops.conv_dgrad_group(dys, wts, [x.shape for x in xs], 3, 1, [None, seed[1].clone(), None, seed[3].clone()],
+                               [False, True, False, True])
+    for i in range(4):
+        y1 = ops.conv_fwd(xs[i], ws[i], None, 3, 1)
+        assert rel(ys[i], y1) < 1e-5
+        dw1 = torch.zeros_like(ws[i])
+        ops.conv_wgrad(xs[i], dys[i], dw1, 3, 1)
+        assert rel(dws[i], dw1) < 2e-5
+        dx1 = ops.conv_dgrad(dys[i], wts[i], xs[i].shape, 3, 1)
+        if i in (1, 3):
+            dx1 = dx1 + seed[i]
+        assert rel(dxs[i], dx1) < 1e-5
