@@ -68,6 +68,11 @@ int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int accumulate
  * running gradient, zeroed by the caller at the start of a step). */
 int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
                      const hrseg_conv_shape_t* s, hrseg_stream_t stream);
+/* all conv weights of a flat parameter buffer at once: `table` (device, 8 ints per entry) lists one
+ * 32x32 (cout,cin) tile of one tap per entry {slot offset, Cout, taps, Cin, co0, ci0, tap, 0}; the
+ * transposed weight of a slot is written at the same offset of flat_t. */
+int hrseg_weight_transpose_all(const float* flat, float* flat_t, const int* table, int nentries,
+                               hrseg_stream_t stream);
 /* Grouped forms: n independent convolutions (the parallel HRNet branches, models.py:524-525) in
  * ONE launch when they can share a kernel instance (channel counts all multiples of 48 or all of
  * 64, stride 1 for dgrad), else n separate launches.  Pointer arrays are HOST arrays. */
@@ -120,6 +125,30 @@ int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int 
                        const float* coef, const float* gamma, float* dgamma, float* dbeta,
                        float* dy, int lddy, float* dres, int lddres, int dres_accumulate,
                        long npix, int C, int eval_mode, hrseg_stream_t stream);
+
+/* Grouped forms: n (1..4) independent BatchNorm problems in three launches (statistics, finalize,
+ * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward. */
+typedef struct {
+  const float* y; int ldy; long npix; int C;       /* conv output [npix][C]                      */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* updated in training  */
+  float momentum, eps;
+  const float* residual; int ldr; int relu;          /* z = relu?(bn(y) + residual)                */
+  float* z; int ldz;
+  float* coef;                                       /* out: [4][C] mean, rstd, scale, shift       */
+  double* partial; int nchunks;                      /* scratch nchunks*2*C doubles (training)     */
+} hrseg_bn_fwd_t;
+int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
+typedef struct {
+  const float* dz; int lddz; const float* z; int ldz; int relu;
+  const float* y; int ldy; const float* coef;
+  float* dgamma; float* dbeta;                       /* += (may be NULL)                            */
+  float* dy; int lddy;                               /* out (may alias dz)                          */
+  float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
+  long npix; int C;
+  double* partial; int nchunks;                      /* scratch (nchunks+1)*2*C doubles             */
+} hrseg_bn_bwd_t;
+int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* problems, int eval_mode, hrseg_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling / resampling / glue
  * nn.MaxPool2d(2) (models.py:140); bilinear align_corners=True resize

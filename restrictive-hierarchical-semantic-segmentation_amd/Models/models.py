@@ -188,10 +188,11 @@ class _EngineModel(nn.Module):
     # -- engine forward ---------------------------------------------------------------------
     def _run(self, x, record):
         run = _Run(self)
+        self._flat.wt_stale = True          # weights may have been updated since the last call
         x_nhwc = Act(ops.nchw_to_nhwc(x.contiguous().float()), needs_grad=False)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
-            rec = Recorder(self.training, record)
+            rec = Recorder(self.training, record, self._flat)
             feats = self._backbone(rec, x_nhwc)
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
@@ -199,7 +200,7 @@ class _EngineModel(nn.Module):
             run.logits.append(z)
             return run
         for L in range(len(self.levels)):
-            rec = Recorder(self.training, record)
+            rec = Recorder(self.training, record, self._flat)
             feats = self._backbone(rec, x_nhwc)
             film = self.films[L - 1] if L > 0 else None
             z, lv = self._head_forward(rec, feats, self._level_head(L), film, run.probs[L - 1] if L > 0 else None, size)

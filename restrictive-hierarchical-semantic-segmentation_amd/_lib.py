@@ -34,6 +34,20 @@ class ConvShape(C.Structure):
     _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride")]
 
 
+class BnFwd(C.Structure):
+    """hrseg_bn_fwd_t"""
+    _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
+                ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
+                ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i)]
+
+
+class BnBwd(C.Structure):
+    """hrseg_bn_bwd_t"""
+    _fields_ = [("dz", _p), ("lddz", _i), ("z", _p), ("ldz", _i), ("relu", _i), ("y", _p), ("ldy", _i), ("coef", _p),
+                ("dgamma", _p), ("dbeta", _p), ("dy", _p), ("lddy", _i), ("dres", _p), ("lddres", _i),
+                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i)]
+
+
 # name -> argtypes, exactly the prototypes of include/hrseg.h
 PROTOTYPES = {
     "hrseg_conv_fwd": [_p, _p, _p, _p, C.POINTER(ConvShape), _p],
@@ -43,12 +57,15 @@ PROTOTYPES = {
     "hrseg_conv_dgrad_group": [_i, _p, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_conv_wgrad_group": [_i, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_weight_transpose": [_p, _p, _i, _i, _i, _p],
+    "hrseg_weight_transpose_all": [_p, _p, _p, _i, _p],
     "hrseg_bn_stats": [_p, _i, _l, _i, _p, _i, _p],
     "hrseg_bn_finalize": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p],
     "hrseg_bn_eval_coef": [_p, _p, _p, _p, _f, _i, _p, _p],
     "hrseg_bn_apply": [_p, _i, _p, _p, _i, _i, _p, _i, _l, _i, _p],
     "hrseg_bn_bwd_reduce": [_p, _i, _p, _i, _i, _p, _i, _p, _l, _i, _p, _i, _p],
     "hrseg_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p],
+    "hrseg_bn_fwd_group": [_i, C.POINTER(BnFwd), _i, _p],
+    "hrseg_bn_bwd_group": [_i, C.POINTER(BnBwd), _i, _p],
     "hrseg_maxpool2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "hrseg_maxpool2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_bilinear_fwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

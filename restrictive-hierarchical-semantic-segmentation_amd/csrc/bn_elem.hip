@@ -536,6 +536,191 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
   }
 }
 
+// =========================================================================== grouped batch norm
+// n independent BatchNorm problems (the parallel HRNet branches, or just one) per launch: block
+// ranges [blk_end[g-1], blk_end[g]) belong to problem g.  Three launches forward (statistics,
+// finalize, apply) and three backward (reduce, finalize, apply) whatever n is.
+#define BN_MAXG 4
+struct BnGroupHdr { int n; int blk_end[BN_MAXG]; };
+__device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nblk) {
+  int g = 0;
+  while (g + 1 < h.n && (int)blockIdx.x >= h.blk_end[g]) ++g;
+  const int lo = g ? h.blk_end[g - 1] : 0;
+  local = blockIdx.x - lo;
+  nblk = h.blk_end[g] - lo;
+  return g;
+}
+struct BnFwdG { BnGroupHdr h; hrseg_bn_fwd_t p[BN_MAXG]; };
+struct BnBwdG { BnGroupHdr h; hrseg_bn_bwd_t p[BN_MAXG]; };
+
+__device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0, const float* __restrict__ zmask,
+                                           int ldz, int relu, const float* __restrict__ yy, int ldy,
+                                           const float* __restrict__ coef, long npix, int C,
+                                           double* __restrict__ partial, int chunk, int nchunks, bool bwd,
+                                           double* red) {
+  // forward: sums of a0 and a0^2; backward: sums of g and g*xhat with g = a0 * (zmask > 0 if relu)
+  const Lanes L = make_lanes(C);
+  const long per = (npix + nchunks - 1) / nchunks;
+  const long lo = (long)chunk * per;
+  const long hi = (lo + per < npix) ? lo + per : npix;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (L.active) {
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
+    if (bwd) {
+      mean = ld4(coef + 4 * L.cq);
+      rstd = ld4(coef + C + 4 * L.cq);
+    }
+    for (long pix = lo + L.pl; pix < hi; pix += L.P) {
+      f32x4 v = ld4(a0 + pix * ld0 + 4 * L.cq);
+      if (!bwd) {
+        s += v;
+        s2 += v * v;
+      } else {
+        if (relu) {
+          const f32x4 zz = ld4(zmask + pix * ldz + 4 * L.cq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = zz[j] > 0.f ? v[j] : 0.f;
+        }
+        const f32x4 xh = (ld4(yy + pix * ldy + 4 * L.cq) - mean) * rstd;
+        s += v;
+        s2 += v * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[threadIdx.x * 8 + j] = s[j];
+    red[threadIdx.x * 8 + 4 + j] = s2[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int pl = 0; pl < L.P; ++pl) {
+      const int t = pl * L.Q + (c >> 2);
+      a += red[t * 8 + (c & 3)];
+      b += red[t * 8 + 4 + (c & 3)];
+    }
+    partial[((size_t)chunk * 2 + 0) * C + c] = a;
+    partial[((size_t)chunk * 2 + 1) * C + c] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_group_kernel(BnFwdG g) {
+  __shared__ double red[256 * 8];
+  int local, nblk;
+  const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  stats_body(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
+  __shared__ double red[512];
+  int local, nblk;
+  const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  const int C = p.C, c = local * 16 + (threadIdx.x & 15);
+  double s, ss;
+  reduce_chunks16(p.partial, p.nchunks, C, c, s, ss, red);
+  if (local == 0 && threadIdx.x == 0 && p.num_batches_tracked) *(long long*)p.num_batches_tracked += 1;
+  if (threadIdx.x >= 16 || c >= C) return;
+  const double mean = s / (double)p.npix;
+  double var = ss / (double)p.npix - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+  p.coef[c] = (float)mean;
+  p.coef[C + c] = rstd;
+  p.coef[2 * C + c] = ga * rstd;
+  p.coef[3 * C + c] = be - (float)mean * ga * rstd;
+  if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+  if (p.running_var) {
+    const double unb = (p.npix > 1) ? var * (double)p.npix / (double)(p.npix - 1) : var;
+    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coef_group_kernel(BnFwdG g) {
+  int local, nblk;
+  const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  const int c = local * 64 + threadIdx.x, C = p.C;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(p.running_var[c] + p.eps);
+  const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+  p.coef[c] = p.running_mean[c];
+  p.coef[C + c] = rstd;
+  p.coef[2 * C + c] = ga * rstd;
+  p.coef[3 * C + c] = be - p.running_mean[c] * ga * rstd;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
+  int local, nblk;
+  const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  const int C = p.C;
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const f32x4 sc = ld4(p.coef + 2 * C + 4 * L.cq), sh = ld4(p.coef + 3 * C + 4 * L.cq);
+  for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
+    f32x4 v = ld4(p.y + pix * p.ldy + 4 * L.cq) * sc + sh;
+    if (p.residual) v += ld4(p.residual + pix * p.ldr + 4 * L.cq);
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st4(p.z + pix * p.ldz + 4 * L.cq, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
+  __shared__ double red[256 * 8];
+  int local, nblk;
+  const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
+  __shared__ double red[512];
+  int local, nblk;
+  const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  const int C = p.C, c = local * 16 + (threadIdx.x & 15);
+  double s, sx;
+  reduce_chunks16(p.partial, p.nchunks, C, c, s, sx, red);
+  if (threadIdx.x >= 16 || c >= C) return;
+  double* totals = p.partial + (size_t)p.nchunks * 2 * C;
+  totals[c] = s;
+  totals[C + c] = sx;
+  if (p.dgamma) p.dgamma[c] += (float)sx;
+  if (p.dbeta) p.dbeta[c] += (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int eval_mode) {
+  int local, nblk;
+  const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
+  const int C = p.C;
+  const Lanes L = make_lanes(C);
+  if (!L.active) return;
+  const double* totals = p.partial + (size_t)p.nchunks * 2 * C;
+  const f32x4 mean = ld4(p.coef + 4 * L.cq), rstd = ld4(p.coef + C + 4 * L.cq), scale = ld4(p.coef + 2 * C + 4 * L.cq);
+  f32x4 mg, mgx;
+  const float inv = eval_mode ? 0.f : (float)(1.0 / (double)p.npix);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mg[j] = (float)(totals[4 * L.cq + j]) * inv;
+    mgx[j] = (float)(totals[C + 4 * L.cq + j]) * inv;
+  }
+  for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
+    f32x4 gg = ld4(p.dz + pix * p.lddz + 4 * L.cq);
+    if (p.relu) {
+      const f32x4 zz = ld4(p.z + pix * p.ldz + 4 * L.cq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gg[j] = zz[j] > 0.f ? gg[j] : 0.f;
+    }
+    const f32x4 xh = (ld4(p.y + pix * p.ldy + 4 * L.cq) - mean) * rstd;
+    st4(p.dy + pix * p.lddy + 4 * L.cq, scale * (gg - mg - xh * mgx));
+    if (p.dres) {
+      float* d = p.dres + pix * p.lddres + 4 * L.cq;
+      st4(d, p.dres_accumulate ? ld4(d) + gg : gg);
+    }
+  }
+}
+
 // =========================================================================== C ABI
 static long chunk_size(long npix, int nchunks) { return (npix + nchunks - 1) / nchunks; }
 
@@ -757,5 +942,71 @@ extern "C" int hrseg_adamw_dev(float* p, const float* g, float* m, float* v, lon
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_dev_kernel, dim3((int)blocks), dim3(256), 0, st, p, g, m, v, n4, n, hyper, state);
   HRSEG_LAUNCH_CHECK("adamw_dev");
+  return 0;
+}
+
+static int check_bn_fwd(const hrseg_bn_fwd_t& p, int training) {
+  if (int e = check_c(p.C, "hrseg_bn_fwd_group")) return e;
+  HRSEG_CHECK_ARG(p.y && p.z && p.coef && p.npix > 0 && p.ldy >= p.C && p.ldz >= p.C && p.ldy % 4 == 0 && p.ldz % 4 == 0,
+                  "hrseg_bn_fwd_group: bad tensor arguments");
+  HRSEG_CHECK_ARG(!training || (p.partial && p.nchunks > 0), "hrseg_bn_fwd_group: training needs partial/nchunks");
+  HRSEG_CHECK_ARG(training || (p.running_mean && p.running_var), "hrseg_bn_fwd_group: eval needs running stats");
+  return 0;
+}
+
+extern "C" int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* probs, int training, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && n <= BN_MAXG && probs, "hrseg_bn_fwd_group: n must be 1..%d", BN_MAXG);
+  hipStream_t st = (hipStream_t)stream;
+  BnFwdG g;
+  g.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (int e = check_bn_fwd(probs[i], training)) return e;
+    g.p[i] = probs[i];
+  }
+  int end = 0;
+  if (training) {
+    for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_stats_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_stats_group");
+    end = 0;
+    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_finalize_group");
+  } else {
+    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 64); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_eval_coef_group_kernel, dim3(end), dim3(64), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_eval_coef_group");
+  }
+  end = 0;
+  for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
+  hipLaunchKernelGGL(bn_apply_group_kernel, dim3(end), dim3(256), 0, st, g);
+  HRSEG_LAUNCH_CHECK("bn_apply_group");
+  return 0;
+}
+
+extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_mode, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && n <= BN_MAXG && probs, "hrseg_bn_bwd_group: n must be 1..%d", BN_MAXG);
+  hipStream_t st = (hipStream_t)stream;
+  BnBwdG g;
+  g.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    const hrseg_bn_bwd_t& p = probs[i];
+    if (int e = check_c(p.C, "hrseg_bn_bwd_group")) return e;
+    HRSEG_CHECK_ARG(p.dz && p.y && p.coef && p.dy && p.partial && (!p.relu || p.z) && p.npix > 0 && p.nchunks > 0,
+                    "hrseg_bn_bwd_group: bad arguments");
+    g.p[i] = p;
+  }
+  int end = 0;
+  for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
+  hipLaunchKernelGGL(bn_bwd_reduce_group_kernel, dim3(end), dim3(256), 0, st, g);
+  HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
+  end = 0;
+  for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+  hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+  HRSEG_LAUNCH_CHECK("bn_bwd_finalize_group");
+  end = 0;
+  for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
+  hipLaunchKernelGGL(bn_bwd_apply_group_kernel, dim3(end), dim3(256), 0, st, g, eval_mode);
+  HRSEG_LAUNCH_CHECK("bn_bwd_apply_group");
   return 0;
 }

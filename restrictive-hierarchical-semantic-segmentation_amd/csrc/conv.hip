@@ -731,6 +731,26 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   }
 }
 
+// every conv weight of the flat parameter buffer in ONE launch: entry e = one 32x32 (co,ci) tile of
+// one tap of one weight; {slot offset, Cout, T, Cin, co0, ci0, tap, -}
+__global__ void weight_transpose_all_kernel(const float* __restrict__ flat, float* __restrict__ flat_t,
+                                            const int* __restrict__ table) {
+  __shared__ float tile[32][33];
+  const int* e = table + (size_t)blockIdx.x * 8;
+  const int off = e[0], Cout = e[1], T = e[2], Cin = e[3], co0 = e[4], ci0 = e[5], t = e[6];
+  const float* w = flat + off;
+  float* wt = flat_t + off;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int co = co0 + j, ci = ci0 + threadIdx.x;
+    tile[j][threadIdx.x] = (co < Cout && ci < Cin) ? w[((size_t)co * T + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + threadIdx.x;
+    if (co < Cout && ci < Cin) wt[((size_t)ci * T + t) * Cout + co] = tile[threadIdx.x][j];
+  }
+}
+
 // --------------------------------------------------------------------------- C ABI
 static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(s != nullptr, "%s: null shape", who);
@@ -990,5 +1010,14 @@ extern "C" int hrseg_weight_transpose(const float* w, float* wt, int Cout, int t
   dim3 grid(ceil_div(Cin, 32), ceil_div(Cout, 32), taps);
   hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, w, wt, Cout, taps, Cin);
   HRSEG_LAUNCH_CHECK("weight_transpose");
+  return 0;
+}
+
+extern "C" int hrseg_weight_transpose_all(const float* flat, float* flat_t, const int* table, int nentries,
+                                          hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(flat && flat_t && table && nentries > 0, "hrseg_weight_transpose_all: bad arguments");
+  hipLaunchKernelGGL(weight_transpose_all_kernel, dim3(nentries), dim3(32, 8), 0, (hipStream_t)stream, flat, flat_t,
+                     table);
+  HRSEG_LAUNCH_CHECK("weight_transpose_all");
   return 0;
 }

@@ -75,6 +75,34 @@ class FlatParams:
                 self.params.append(p)
         self._first, self._last = self.params[0], self.params[-1]
         self.grads_fresh = True   # flat grad is all zeros
+        # transposed copies of every conv weight (the data-gradient operand), refreshed once per step
+        import numpy as np
+        entries = []
+        for (name, p), off in zip(params, offs):
+            if p.dim() != 4:
+                continue
+            o, i, kh, kw = p.shape
+            if i % 16 or o % 16:
+                continue                                   # image layer / heads: no MFMA data-gradient
+            for t in range(kh * kw):
+                for co0 in range(0, o, 32):
+                    for ci0 in range(0, i, 32):
+                        entries.append((off, o, kh * kw, i, co0, ci0, t, 0))
+            p._hr_tstore_range = (off, off + p.numel())
+        self.data_t = torch.empty_like(self.data)
+        self._wt_table = torch.from_numpy(np.asarray(entries, dtype=np.int32).reshape(-1)).to(device) if entries else None
+        self._wt_entries = len(entries)
+        self.wt_stale = True
+
+    def transposed(self, p):
+        """[Cin][taps][Cout] copy of conv weight p (valid until the next forward)"""
+        if self.wt_stale:
+            if self._wt_table is not None:
+                ops.call("hrseg_weight_transpose_all", ops.ptr(self.data), ops.ptr(self.data_t), ops.ptr(self._wt_table),
+                         self._wt_entries)
+            self.wt_stale = False
+        lo, hi = p._hr_tstore_range
+        return self.data_t[lo:hi]
 
     def valid(self, device):
         """False once .to()/.cuda() rebound the parameters to fresh storages."""
@@ -96,10 +124,11 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record):
+    def __init__(self, training, record, flat=None):
         self.training = training
         self.record = record
         self.tape = []
+        self.flat = flat
         self.wt_cache = {}
 
     # ------------------------------------------------------------------ helpers
@@ -122,6 +151,8 @@ class Recorder:
                 fn()
 
     def _wt(self, conv):
+        if self.flat is not None and hasattr(conv.weight, "_hr_tstore_range"):
+            return self.flat.transposed(conv.weight)
         key = id(conv)
         wt = self.wt_cache.get(key)
         if wt is None:
@@ -137,68 +168,38 @@ class Recorder:
 
     # ------------------------------------------------------------------ conv + BN (+residual) (+ReLU)
     def conv_bn(self, x, conv, bn, relu, residual=None, out=None):
-        k, s = conv.kernel_size[0], conv.stride[0]
-        bias = conv.bias._hr_store if conv.bias is not None else None
-        y = ops.conv_fwd(x.data, conv.weight._hr_store, bias, k, s, cout=conv.out_channels)
-        if self.training:
-            coef = ops.bn_train_coef(y, bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, bn.momentum, bn.eps)
-        else:
-            coef = ops.bn_eval_coef(bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var, bn.eps)
-        z = Act(ops.bn_apply(y, coef, residual.data if residual is not None else None, relu, out=out))
-        if not self.record:
-            return z
-        eval_mode = not self.training
+        return self.conv_bn_group([(x, conv, bn, residual)], relu, outs=[out])[0]
 
-        def bwd():
-            dz = z.grad
-            z.grad = None
-            dres, dres_acc = None, False
-            if residual is not None and residual.needs_grad:
-                if residual.grad is None:
-                    residual.grad = torch.empty(residual.data.shape, dtype=torch.float32, device=dz.device)
-                else:
-                    dres_acc = True
-                dres = residual.grad
-            dy = ops.bn_bwd(dz, z.data, relu, y, coef, bn.weight._hr_gstore, bn.bias._hr_gstore, dres, dres_acc,
-                            eval_mode, dy_out=dz)
-            ops.conv_wgrad(x.data, dy, conv.weight._hr_gstore, k, s)
-            if x.needs_grad:
-                if x.grad is None:
-                    x.grad = ops.conv_dgrad(dy, self._wt(conv), x.data.shape, k, s)
-                else:
-                    ops.conv_dgrad(dy, self._wt(conv), x.data.shape, k, s, out=x.grad, accumulate=True)
-        self._push(bwd)
-        return z
-
-    def conv_bn_group(self, items, relu):
-        """items: list of (x, conv, bn, residual-or-None) that are independent of each other (the
-        parallel HRNet branches): the convolutions, their weight gradients and their data gradients
-        each go out as ONE grouped launch."""
-        if len(items) == 1:
-            x, conv, bn, res = items[0]
-            return [self.conv_bn(x, conv, bn, relu, res)]
+    def conv_bn_group(self, items, relu, outs=None):
+        """items: list of (x, conv, bn, residual-or-None), independent of each other (the parallel
+        HRNet branches; a single layer is a group of one).  Per group: one conv launch, three BN
+        launches; backward: three BN launches, one wgrad launch, one dgrad launch."""
+        n = len(items)
         k, s = items[0][1].kernel_size[0], items[0][1].stride[0]
         assert all(c.kernel_size[0] == k and c.stride[0] == s for _, c, _, _ in items)
         xs = [it[0] for it in items]
-        ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
-                                [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
-                                [c.out_channels for _, c, _, _ in items])
-        zs, coefs = [], []
-        for (x, conv, bn, res), y in zip(items, ys):
-            if self.training:
-                coef = ops.bn_train_coef(y, bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var,
-                                         bn.num_batches_tracked, bn.momentum, bn.eps)
-            else:
-                coef = ops.bn_eval_coef(bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var, bn.eps)
-            coefs.append(coef)
-            zs.append(Act(ops.bn_apply(y, coef, res.data if res is not None else None, relu)))
+        if n == 1:
+            conv = items[0][1]
+            ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
+                               k, s, cout=conv.out_channels)]
+        else:
+            ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
+                                    [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
+                                    [c.out_channels for _, c, _, _ in items])
+        bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
+                         nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
+                         residual=res.data if res is not None else None, relu=relu,
+                         out=outs[i] if outs is not None else None)
+                    for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
+        zc = ops.bn_fwd_group(bn_items, self.training)
+        zs = [Act(z) for z, _ in zc]
         if not self.record:
             return zs
+        coefs = [c for _, c in zc]
         eval_mode = not self.training
 
         def bwd():
-            dys = []
+            bw = []
             for (x, conv, bn, res), y, z, coef in zip(items, ys, zs, coefs):
                 dz = z.grad
                 z.grad = None
@@ -209,15 +210,26 @@ class Recorder:
                     else:
                         dres_acc = True
                     dres = res.grad
-                dys.append(ops.bn_bwd(dz, z.data, relu, y, coef, bn.weight._hr_gstore, bn.bias._hr_gstore, dres,
-                                      dres_acc, eval_mode, dy_out=dz))
-            ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
+                bw.append(dict(dz=dz, z=z.data, relu=relu, y=y, coef=coef, dgamma=bn.weight._hr_gstore,
+                               dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc))
+            dys = ops.bn_bwd_group(bw, eval_mode)
             need = [i for i, x in enumerate(xs) if x.needs_grad]
+            if n == 1:
+                conv = items[0][1]
+                ops.conv_wgrad(xs[0].data, dys[0], conv.weight._hr_gstore, k, s)
+                if need:
+                    x = xs[0]
+                    if x.grad is None:
+                        x.grad = ops.conv_dgrad(dys[0], self._wt(conv), x.data.shape, k, s)
+                    else:
+                        ops.conv_dgrad(dys[0], self._wt(conv), x.data.shape, k, s, out=x.grad, accumulate=True)
+                return
+            ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
             if need:
-                outs = ops.conv_dgrad_group([dys[i] for i in need], [self._wt(items[i][1]) for i in need],
-                                            [xs[i].data.shape for i in need], k, s, [xs[i].grad for i in need],
-                                            [xs[i].grad is not None for i in need])
-                for i, o in zip(need, outs):
+                got = ops.conv_dgrad_group([dys[i] for i in need], [self._wt(items[i][1]) for i in need],
+                                           [xs[i].data.shape for i in need], k, s, [xs[i].grad for i in need],
+                                           [xs[i].grad is not None for i in need])
+                for i, o in zip(need, got):
                     xs[i].grad = o
         self._push(bwd)
         return zs

@@ -196,6 +196,64 @@ def bn_bwd(dz, z, relu, y, coef, dgamma, dbeta, dres=None, dres_accumulate=False
     return dy
 
 
+def bn_fwd_group(items, training):
+    """items: list of dict(y, gamma, beta, rm, rv, nbt, momentum, eps, residual, relu[, out]);
+    -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply)."""
+    n = len(items)
+    arr = (_lib.BnFwd * n)()
+    outs = []
+    for a, it in zip(arr, items):
+        y = it["y"]
+        Cn, npix = y.shape[3], _npix(y)
+        z = it.get("out")
+        if z is None:
+            z = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        coef = torch.empty(4 * Cn, dtype=torch.float32, device=y.device)
+        res = it.get("residual")
+        a.y, a.ldy, a.npix, a.C = ptr(y), _ld(y), npix, Cn
+        a.gamma, a.beta = ptr(it["gamma"]), ptr(it["beta"])
+        a.running_mean, a.running_var = ptr(it["rm"]), ptr(it["rv"])
+        a.num_batches_tracked = ptr(it["nbt"]) if training else None
+        a.momentum, a.eps = float(it["momentum"]), float(it["eps"])
+        a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
+        a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
+        if training:
+            nch = _nchunks(npix, Cn)
+            part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
+            a.partial, a.nchunks = ptr(part), nch
+            outs.append((z, coef, part))
+        else:
+            a.partial, a.nchunks = None, 0
+            outs.append((z, coef, None))
+    call("hrseg_bn_fwd_group", n, arr, int(training))
+    return [(z, coef) for z, coef, _ in outs]
+
+
+def bn_bwd_group(items, eval_mode):
+    """items: list of dict(dz, z, relu, y, coef, dgamma, dbeta, dres, dres_accumulate); dy is written
+    in place over dz.  Three launches for the whole list."""
+    n = len(items)
+    arr = (_lib.BnBwd * n)()
+    keep = []
+    for a, it in zip(arr, items):
+        y, dz, z = it["y"], it["dz"], it["z"]
+        Cn, npix = y.shape[3], _npix(y)
+        nch = _nchunks(npix, Cn)
+        part = torch.empty((nch + 1) * 2 * Cn, dtype=torch.float64, device=y.device)
+        keep.append(part)
+        dres = it.get("dres")
+        a.dz, a.lddz = ptr(dz), _ld(dz)
+        a.z, a.ldz, a.relu = (ptr(z) if it["relu"] else None), (_ld(z) if it["relu"] else 0), int(it["relu"])
+        a.y, a.ldy, a.coef = ptr(y), _ld(y), ptr(it["coef"])
+        a.dgamma, a.dbeta = ptr(it["dgamma"]), ptr(it["dbeta"])
+        a.dy, a.lddy = ptr(dz), _ld(dz)
+        a.dres, a.lddres = ptr(dres), (_ld(dres) if dres is not None else 0)
+        a.dres_accumulate = int(bool(it.get("dres_accumulate", False)))
+        a.npix, a.C, a.partial, a.nchunks = npix, Cn, ptr(part), nch
+    call("hrseg_bn_bwd_group", n, arr, int(eval_mode))
+    return [it["dz"] for it in items]
+
+
 # ------------------------------------------------------------------ pooling / resize / glue
 def maxpool2_fwd(x):
     B, H, W, Cn = x.shape

@@ -126,7 +126,9 @@ def test_train_steps_track_the_oracle(name):
             continue
         # two steps at lr=1e-4: an element whose gradient is pure rounding noise may move by
         # +-lr per step in either evaluation, i.e. differ by up to 4e-4
-        assert float((a - b).abs().max()) < 4.5e-4 + 1e-3 * float(b.abs().max()), n
+        # BN running statistics of the second step are taken on activations of the perturbed weights
+        tol = 1e-2 if "running_" in n else 1e-3
+        assert float((a - b).abs().max()) < 4.5e-4 + tol * float(b.abs().max()), n
 
 
 def test_missing_library_is_loud(tmp_path, monkeypatch):
