@@ -978,7 +978,7 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   const int T = s->ksize * s->ksize;
   if (s->Cin <= 4) {
     const long M = (long)s->B * s->Ho * s->Wo;
-    const int ppb = 512;
+    const int ppb = 64;   // many short pixel ranges: the per-thread loop is latency-bound
     dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
     hipLaunchKernelGGL(conv_small_cin_wgrad_kernel, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi,
                        s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, ppb);

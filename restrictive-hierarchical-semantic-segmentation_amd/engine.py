@@ -178,6 +178,7 @@ class Recorder:
         k, s = items[0][1].kernel_size[0], items[0][1].stride[0]
         assert all(c.kernel_size[0] == k and c.stride[0] == s for _, c, _, _ in items)
         xs = [it[0] for it in items]
+        assert len({id(x) for x in xs}) == n, "a group must not read one tensor twice (data gradients would race)"
         if n == 1:
             conv = items[0][1]
             ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,

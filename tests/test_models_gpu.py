@@ -127,8 +127,11 @@ def test_train_steps_track_the_oracle(name):
         # two steps at lr=1e-4: an element whose gradient is pure rounding noise may move by
         # +-lr per step in either evaluation, i.e. differ by up to 4e-4
         # BN running statistics of the second step are taken on activations of the perturbed weights
-        tol = 1e-2 if "running_" in n else 1e-3
-        assert float((a - b).abs().max()) < 4.5e-4 + tol * float(b.abs().max()), n
+        if "running_" in n:
+            # (the lowest-resolution branch normalises over 8 samples here: compare in the L2 sense)
+            assert float((a - b).norm()) < 2e-2 * float(b.norm()) + 1e-4, n
+            continue
+        assert float((a - b).abs().max()) < 4.5e-4 + 1e-3 * float(b.abs().max()), n
 
 
 def test_missing_library_is_loud(tmp_path, monkeypatch):
