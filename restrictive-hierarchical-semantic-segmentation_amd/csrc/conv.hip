@@ -157,11 +157,17 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
       if (tid + 256 * i < B_F4) *reinterpret_cast<f32x4*>(base + b_st[i]) = rb[i];
   };
 
-  f32x4 acc[WTN][WTM];
+  // v_mfma_f32_16x16x4_f32 only reaches its issue rate with ~12 independent accumulators in
+  // flight (measured: 4 chains 95 TF, 12 chains 150 TF, tools/ubench/mfma_peak.hip), so the k-steps
+  // of a chunk go to KP separate partial accumulators per output tile, summed in the epilogue.
+  constexpr int KP = (WTM * WTN <= 3) ? 4 : (WTM * WTN <= 6) ? 2 : 1;
+  f32x4 acc[KP][WTN][WTM];
 #pragma unroll
-  for (int n = 0; n < WTN; ++n)
+  for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
-    for (int m = 0; m < WTM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < WTN; ++n)
+#pragma unroll
+      for (int m = 0; m < WTM; ++m) acc[kp][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offset of this lane inside a 16-row tile
   const int frow = lane & 15;
@@ -192,7 +198,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
         for (int n = 0; n < WTN; ++n)
 #pragma unroll
           for (int m = 0; m < WTM; ++m)
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[n][m], 0, 0, 0);
+            acc[k % KP][n][m] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[k % KP][n][m], 0, 0, 0);
     }
     if (DB == 1) __syncthreads();  // every wave is done reading before the buffer is rewritten
     if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
@@ -214,7 +221,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
 #pragma unroll
     for (int n = 0; n < WTN; ++n) {
       const int ch = n0 + 16 * n + 4 * g;
-      f32x4 v = acc[n][m];
+      f32x4 v = acc[0][n][m];
+#pragma unroll
+      for (int kp = 1; kp < KP; ++kp) v += acc[kp][n][m];
       if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
       if (split) {
 #pragma unroll
@@ -556,11 +565,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
     }
   };
 
-  f32x4 acc[TN][TK];
+  constexpr int KP = (TN * TK <= 9) ? 2 : 1;     // independent accumulation chains, see igemm_body
+  f32x4 acc2[KP][TN][TK];
 #pragma unroll
-  for (int n = 0; n < TN; ++n)
+  for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
-    for (int k = 0; k < TK; ++k) acc[n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int k = 0; k < TK; ++k) acc2[kp][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nstages > 0) {
     stage_load(0);
@@ -584,7 +596,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
       for (int n = 0; n < TN; ++n)
 #pragma unroll
         for (int k = 0; k < TK; ++k)
-          acc[n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n], bf[k], acc[n][k], 0, 0, 0);
+          acc2[ks4 % KP][n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n], bf[k], acc2[ks4 % KP][n][k], 0, 0, 0);
     }
     if (DB == 1) __syncthreads();
     if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
@@ -595,9 +607,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
 #pragma unroll
   for (int n = 0; n < TN; ++n)
 #pragma unroll
-    for (int k = 0; k < TK; ++k)
+    for (int k = 0; k < TK; ++k) {
+      f32x4 v = acc2[0][n][k];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lds[((wave * TN + n) * TK + k) * 256 + r * 64 + lane] = acc[n][k][r];
+      for (int kp = 1; kp < KP; ++kp) v += acc2[kp][n][k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[((wave * TN + n) * TK + k) * 256 + r * 64 + lane] = v[r];
+    }
   __syncthreads();
   const int r = tid >> 6, l = tid & 63;
 #pragma unroll
