@@ -226,7 +226,9 @@ def main():
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
         line = {
-            "metric": "train images/sec (620x620, hier-HRNet-W48)", "value": round(ips, 3), "unit": "images/s",
+            "metric": "train images/sec (620x620, hier-HRNet-W48)" if (args.model == "hrnet" and hier) else
+            "train images/sec (%dx%d, %s%s)" % (args.size, args.size, "hier-" if hier else "flat-", args.model),
+            "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %s (%s), %dx%d, batch %d per GPU, full train step (fwd L passes, metrics, "

@@ -101,7 +101,15 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box: HRSEG_DIST_BACKEND=gloo with HRSEG_FORCE_DEVICE=0 runs
+    # several ranks on one card (RCCL refuses two ranks per device); production is nccl = RCCL
+    backend = os.environ.get("HRSEG_DIST_BACKEND", "nccl")
+    if "HRSEG_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["HRSEG_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return rank, local, world
