@@ -87,6 +87,8 @@ int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy,
 /* tuning/debug: override the implicit-GEMM tile plan (0 = automatic) -- pixel tiles per wave
  * (1,2,4), 16-channel K chunks per stage (1-3), LDS buffers (1,2), split-K factor */
 int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);
+/* experimental halo-patch kernel for 3x3 stride-1 convolutions: 0 = off (default), 1 = automatic */
+int hrseg_debug_set_patch_mode(int mode);
 /* same for the weight-gradient kernel: pixels per LDS stage (64,128), LDS buffers, target grid size */
 int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks);
 /* wt[ci][t][co] = w[co][t][ci] */
@@ -242,6 +244,11 @@ int hrseg_loss_bwd(const float* z, const float* t, const float* coef, const floa
 int hrseg_consistency(const float* p, const float* pprev, double* out, int B, int C, int Cprev,
                       long hw, int ngroups, const int* group_parent, const int* group_size,
                       hrseg_stream_t stream);
+/* gradient of  scale * sum_groups sum_{b,pix} |...|  times the device scalar g[0]:
+ * dp [B,C,hw] and dpprev [B,Cprev,hw] are written */
+int hrseg_consistency_bwd(const float* p, const float* pprev, const float* g, float scale, float* dp,
+                          float* dpprev, int B, int C, int Cprev, long hw, int ngroups,
+                          const int* group_parent, const int* group_size, hrseg_stream_t stream);
 /* argmax one-hot of z masked by t!=-1, plus confusion matrix counts
  * cm[(C+child)*(C+child)] (int64, +=) of (target label, predicted label) with
  * the synthetic background class 0 for child levels. mask_pred=1 is the train

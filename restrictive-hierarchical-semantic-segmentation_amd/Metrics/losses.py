@@ -97,17 +97,31 @@ def _level_groups(levels, parent_of, L):
     return out
 
 
-def hierarchical_consistency_loss(probs_per_level, levels, parent_of, reduction="mean"):
-    """mean_{b,h,w} |sum_children P_c - P_p| averaged over parents (losses.py:150-177).
+class _LevelConsistency(torch.autograd.Function):
+    """sum over the level's parent groups of (mean or sum over b,h,w of) |sum_children P - P_parent|"""
 
-    Forward on the GPU (hrseg_consistency).  In the training loop the inputs are
-    one-hot predictions and carry no gradient; inputs that require
-    grad are rejected rather than silently detached."""
+    @staticmethod
+    def forward(ctx, cur, prev, gp, gs, scale):
+        cur, prev = cur.contiguous(), prev.contiguous()
+        sums = ops.consistency_sums(cur, prev, gp, gs)
+        ctx.save_for_backward(cur, prev)
+        ctx.meta = (gp, gs, scale)
+        return (sums.sum() * scale).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        cur, prev = ctx.saved_tensors
+        gp, gs, scale = ctx.meta
+        dcur, dprev = ops.consistency_bwd(cur, prev, g.reshape(1).float().contiguous(), scale, gp, gs)
+        return dcur, dprev, None, None, None
+
+
+def hierarchical_consistency_loss(probs_per_level, levels, parent_of, reduction="mean"):
+    """mean_{b,h,w} |sum_children P_c - P_p| averaged over parents (losses.py:150-177), forward and
+    gradient on the GPU (hrseg_consistency, hrseg_consistency_bwd).  In the training loop the inputs
+    are one-hot predictions without gradient; probabilities that require grad get theirs."""
     if probs_per_level is None or levels is None or parent_of is None:
         return probs_per_level[0].sum() * 0 if probs_per_level else 0.0
-    if any(p.requires_grad for p in probs_per_level):
-        raise NotImplementedError("hierarchical_consistency_loss: gradient w.r.t. probabilities is not built; "
-                                  "pass detached probabilities (the reference loop passes one-hot predictions)")
     total, count = None, 0
     for L in range(1, len(levels)):
         groups = _level_groups(levels, parent_of, L)
@@ -118,11 +132,11 @@ def hierarchical_consistency_loss(probs_per_level, levels, parent_of, reduction=
             [c for _, ch in groups for c in ch] == list(range(cur.shape[1]))
         if not contiguous:
             raise NotImplementedError("children of a parent must occupy consecutive channels (BFS channel order)")
-        sums = ops.consistency_sums(cur, prev, [p for p, _ in groups], [len(ch) for _, ch in groups])
         n = cur.shape[0] * cur.shape[2] * cur.shape[3]
-        part = sums.sum() / n if reduction == "mean" else sums.sum()
+        scale = 1.0 / n if reduction == "mean" else 1.0
+        part = _LevelConsistency.apply(cur, prev, [p for p, _ in groups], [len(ch) for _, ch in groups], scale)
         total = part if total is None else total + part
         count += len(groups)
     if count == 0:
         return probs_per_level[0].sum() * 0
-    return (total / count).float()
+    return total / count

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "hrseg_loss_finalize": [_p, _p, _i, _i, _p, _p, _p],
     "hrseg_loss_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _p],
     "hrseg_consistency": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_consistency_bwd": [_p, _p, _p, _f, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
     "hrseg_predict_metrics": [_p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     "hrseg_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     "hrseg_adamw_dev": [_p, _p, _p, _p, _l, _p, _p, _p],

@@ -312,7 +312,8 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
     pl.ksplit = (int)((448 + blocks - 1) / blocks);
     if (pl.ksplit > nstages / 3) pl.ksplit = nstages / 3;
   }
-  if (g_tune_wtm) pl.wtm = g_tune_wtm;
+  if (g_tune_wtm >= 10 && a.N % 96 == 0) pl.wtn = 6;   // tuning: tens digit 1 = 96-channel tiles
+  if (g_tune_wtm % 10) pl.wtm = g_tune_wtm % 10;
   if (g_tune_kc && a.K % (16 * g_tune_kc) == 0) pl.kc = g_tune_kc;
   if (g_tune_db) pl.db = g_tune_db;
   if (g_tune_ksplit) pl.ksplit = g_tune_ksplit;
@@ -331,7 +332,7 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
   if (pl.wtm == M_ && pl.wtn == N_ && pl.kc == K_ && pl.db == D_) { launch_igemm<M_, N_, K_, D_>(a, pl.ksplit, st); return 0; }
 #define IG3(M_, N_, K_) IG4(M_, N_, K_, 1) IG4(M_, N_, K_, 2)
 #define IG2(M_, N_) IG3(M_, N_, 1) IG3(M_, N_, 2) IG3(M_, N_, 3)
-#define IG1(M_) IG2(M_, 1) IG2(M_, 2) IG2(M_, 3) IG2(M_, 4)
+#define IG1(M_) IG2(M_, 1) IG2(M_, 2) IG2(M_, 3) IG2(M_, 4) IG2(M_, 6)
   IG1(1) IG1(2) IG1(4)
 #undef IG1
 #undef IG2
@@ -339,6 +340,186 @@ static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
 #undef IG4
   hrseg_set_error("igemm: no kernel for plan wtm=%d wtn=%d kc=%d db=%d", pl.wtm, pl.wtn, pl.kc, pl.db);
   return HRSEG_ERR_UNSUPPORTED;
+}
+
+// --------------------------------------------------------------------------- 3x3 stride-1: halo-patch kernel
+// The im2col kernel above pulls every input pixel through the vector-memory path nine times; an
+// in-kernel stamp profile (tools/ubench/igemm_lab.hip) shows its waves stalled at ISSUING global loads
+// for a third of each stage: the per-CU texture-address path, not HBM or MFMA, is the limit.  For 3x3
+// stride-1 convolutions (forward and data-gradient: 80 % of the HRNet FLOPs, all of UNet's) this
+// kernel stages a (TH+2) x 18 input patch per 16-channel chunk ONCE and lets the nine taps read it
+// from LDS with shifted row addresses: 2.6x fewer load instructions per MFMA.
+//   block = TH x 16 output pixels x 16*WTN channels, 4 waves x (TH/4) pixel rows each;
+//   LDS: patch [(TH+2)*18 rows][20 floats] (80-byte rows spread the banks), weights [9][BN][16] swizzled.
+struct PatchArgs {
+  const float* x; const float* w; const float* bias; float* y;
+  int ldx, ldy, B, H, W, K, N;   // input/output images are H x W (stride 1, pad 1)
+  int tiles_x, tiles_y;
+  int flip;                      // 1: data-gradient geometry (tap t reads the patch at tap 8-t)
+  int accumulate;
+};
+
+template <int TH, int WTN>
+__global__ __launch_bounds__(256) void igemm_patch_kernel(PatchArgs p) {
+  constexpr int BN = 16 * WTN, PW = 18, PROWS = (TH + 2) * PW, PSTR = 20;
+  constexpr int P_F4 = PROWS * 4, W_F4 = BN * 9 * 4;
+  constexpr int P_LOADS = (P_F4 + 255) / 256, W_LOADS = (W_F4 + 255) / 256;
+  constexpr int RPW = TH / 4;                       // pixel rows (16-pixel MFMA tiles) per wave
+  constexpr int KP = (RPW * WTN <= 3) ? 4 : (RPW * WTN <= 6) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[PROWS * PSTR + BN * 9 * 16];
+  float* lp = lds;
+  float* lw = lds + PROWS * PSTR;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = p.N / BN;
+  const int nblk = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, nblk);
+  const int nt = wg % ntn;
+  int mt = wg / ntn;
+  const int tx = mt % p.tiles_x;
+  mt /= p.tiles_x;
+  const int ty = mt % p.tiles_y, b = mt / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16, n0 = nt * BN;
+
+  // per-thread load slots, fixed for the whole kernel (only the channel offset moves)
+  long p_off[P_LOADS];
+  int p_st[P_LOADS];
+#pragma unroll
+  for (int i = 0; i < P_LOADS; ++i) {
+    const int f = tid + 256 * i;
+    const int r = f >> 2, q = f & 3;
+    const int py = r / PW, px = r - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = (f < P_F4) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+    p_off[i] = ok ? ((long)(b * p.H + iy) * p.W + ix) * p.ldx + 4 * q : -1;
+    p_st[i] = (f < P_F4) ? r * PSTR + 4 * q : -1;
+  }
+  long w_off[W_LOADS];
+  int w_st[W_LOADS];
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    const int f = tid + 256 * i;
+    const int r = f >> 2, q = f & 3;          // r = tap*BN + n
+    const int tap = r / BN, n = r - tap * BN;
+    w_off[i] = (f < W_F4) ? ((long)(n0 + n) * 9 + tap) * p.K + 4 * q : -1;
+    w_st[i] = (f < W_F4) ? r * 16 + 4 * lds_slot(n, q) : -1;
+  }
+
+  f32x4 rp[P_LOADS], rw[W_LOADS];
+  // load slot j of the combined list (patch slots first); part = tap index: the per-CU load path
+  // takes ~40 cycles per wave-wide 16-byte load, and a wave that issues its ten loads back to back
+  // sits blocked at the issue port for thousands of cycles (tools/ubench/patch_lab.hip) -- so the
+  // next stage's loads go out one or two per tap, between the MFMA runs.
+  auto stage_load_part = [&](int c0, int part, int nparts) {
+#pragma unroll
+    for (int i = 0; i < P_LOADS; ++i)
+      if (i % nparts == part) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p_off[i] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + p_off[i] + c0);
+        rp[i] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i)
+      if ((P_LOADS + i) % nparts == part) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (w_off[i] >= 0) v = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + c0);
+        rw[i] = v;
+      }
+  };
+  auto stage_load = [&](int c0) { stage_load_part(c0, 0, 1); };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_LOADS; ++i)
+      if (p_st[i] >= 0) *reinterpret_cast<f32x4*>(lp + p_st[i]) = rp[i];
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i)
+      if (w_st[i] >= 0) *reinterpret_cast<f32x4*>(lw + w_st[i]) = rw[i];
+  };
+
+  f32x4 acc[KP][WTN][RPW];
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+    for (int n = 0; n < WTN; ++n)
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) acc[kp][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fh = lane >> 4;
+  const int woff = fi * 16 + 4 * lds_slot(fi, fh);    // weight fragment (aligned 16-row tiles)
+  const int nchunks = p.K >> 4;
+  stage_load(0);
+  stage_store();
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (more) stage_load_part((c + 1) << 4, t, 9);
+      const int gt = p.flip ? 8 - t : t;
+      const int kh = gt / 3, kw = gt - 3 * kh;
+      f32x4 xf[RPW], wf[WTN];
+#pragma unroll
+      for (int m = 0; m < RPW; ++m)
+        xf[m] = *reinterpret_cast<const f32x4*>(lp + ((wave * RPW + m + kh) * PW + kw + fi) * PSTR + 4 * fh);
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) wf[n] = *reinterpret_cast<const f32x4*>(lw + (t * BN + 16 * n) * 16 + woff);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int n = 0; n < WTN; ++n)
+#pragma unroll
+          for (int m = 0; m < RPW; ++m)
+            acc[k % KP][n][m] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[k % KP][n][m], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) stage_store();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int m = 0; m < RPW; ++m) {
+    const int oy = y0 + wave * RPW + m, ox = x0 + fi;
+    if (oy >= p.H || ox >= p.W) continue;
+    float* yrow = p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy;
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      const int ch = n0 + 16 * n + 4 * fh;
+      f32x4 v = acc[0][n][m];
+#pragma unroll
+      for (int kp = 1; kp < KP; ++kp) v += acc[kp][n][m];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+      *reinterpret_cast<f32x4*>(yrow + ch) = v;
+    }
+  }
+}
+
+static int g_patch_mode = 0;   // 0 = off (default: measured no faster than im2col), 1 = automatic
+extern "C" int hrseg_debug_set_patch_mode(int mode) { g_patch_mode = mode; return 0; }
+
+// returns 1 if the problem is not a patch-kernel case (caller uses the im2col kernel)
+static int dispatch_patch(const IgemmArgs& a, int flip, hipStream_t st) {
+  if (!g_patch_mode || a.T != 9 || a.ntaps != 9 || a.sy != 1 || a.oys != 1 || a.Hi != a.Ho || a.Wi != a.Wo) return 1;
+  const int wtn = (a.N % 48 == 0) ? 3 : (a.N % 64 == 0) ? 4 : 0;
+  if (!wtn) return 1;
+  const int tiles_x = ceil_div(a.Wo, 16);
+  // tile rows: 8 when that still gives >= 2 blocks per CU and wastes < 15 % of the rows, else 4
+  const int ntn = a.N / (16 * wtn);
+  int th = 8;
+  if ((long)a.B * ceil_div(a.Ho, 8) * tiles_x * ntn < 512 || ceil_div(a.Ho, 8) * 8 > a.Ho * 1.15) th = 4;
+  const long blocks = (long)a.B * ceil_div(a.Ho, th) * tiles_x * ntn;
+  const double waste = (double)(ceil_div(a.Ho, th) * th) * (tiles_x * 16) / ((double)a.Ho * a.Wo);
+  if (blocks < 384 || waste > 1.35) return 1;       // small images: im2col + split-K does better
+  PatchArgs p;
+  p.x = a.x; p.w = a.w; p.bias = a.bias; p.y = a.y; p.ldx = a.ldx; p.ldy = a.ldy;
+  p.B = a.B; p.H = a.Ho; p.W = a.Wo; p.K = a.K; p.N = a.N;
+  p.tiles_x = tiles_x; p.tiles_y = ceil_div(a.Ho, th); p.flip = flip; p.accumulate = a.accumulate;
+  if (th == 8 && wtn == 3) hipLaunchKernelGGL((igemm_patch_kernel<8, 3>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else if (th == 8) hipLaunchKernelGGL((igemm_patch_kernel<8, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else if (wtn == 3) hipLaunchKernelGGL((igemm_patch_kernel<4, 3>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_patch_kernel<4, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return 0;
 }
 
 // group dispatch: one common plan (64-pixel tiles, widest K stage, single LDS buffer); problems whose
@@ -939,6 +1120,10 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
+  if (dispatch_patch(a, 0, st) == 0) {
+    HRSEG_LAUNCH_CHECK("igemm_patch(fwd)");
+    return 0;
+  }
   if (int e = dispatch_igemm(a, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;
@@ -964,6 +1149,10 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
     int oy[9], ox[9], wtp[9];
     for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
     pack_taps(a, a.T, oy, ox, wtp);
+    if (dispatch_patch(a, 1, st) == 0) {
+      HRSEG_LAUNCH_CHECK("igemm_patch(dgrad)");
+      return 0;
+    }
     if (int e = dispatch_igemm(a, st)) return e;
     HRSEG_LAUNCH_CHECK("igemm_conv(dgrad)");
     return 0;

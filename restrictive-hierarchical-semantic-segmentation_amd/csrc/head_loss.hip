@@ -594,6 +594,35 @@ __global__ __launch_bounds__(256) void consistency_kernel(const float* __restric
               (double)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// gradient of sum_g (scale_g) * sum_pix |sum_{c in g} P[c] - Pprev[parent_g]|:
+// dP[c] = g*scale*sign(diff), dPprev[parent] -= g*scale*sign(diff); upstream scalar g on the device
+__global__ void consistency_bwd_kernel(const float* __restrict__ p, const float* __restrict__ pprev,
+                                       const float* __restrict__ gup, float scale, float* __restrict__ dp,
+                                       float* __restrict__ dpprev, int C, int Cprev, long hw, long n, Groups g) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long b = i / hw, pix = i - b * hw;
+  const float gs = gup[0] * scale;
+  float dpar[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) dpar[c] = 0.f;
+  int start = 0;
+  for (int gi = 0; gi < g.n; ++gi) {
+    float s = 0.f;
+    for (int c = 0; c < g.size[gi]; ++c) s += p[((size_t)b * C + start + c) * hw + pix];
+    const float d = s - pprev[((size_t)b * Cprev + g.parent[gi]) * hw + pix];
+    const float sg = (d > 0.f) ? gs : (d < 0.f ? -gs : 0.f);
+    for (int c = 0; c < g.size[gi]; ++c) dp[((size_t)b * C + start + c) * hw + pix] = sg;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c == g.parent[gi]) dpar[c] -= sg;
+    start += g.size[gi];
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < Cprev) dpprev[((size_t)b * Cprev + c) * hw + pix] = dpar[c];
+}
+
 // argmax one-hot (masked by t != -1) and confusion counts cm[target][pred]
 template <int CT>
 __global__ __launch_bounds__(256) void predict_metrics_kernel(const float* __restrict__ z, const float* __restrict__ t,
@@ -871,5 +900,20 @@ extern "C" int hrseg_predict_metrics(const float* z, const float* t, float* oneh
   else if (C <= 8) hipLaunchKernelGGL((predict_metrics_kernel<8>), grid, dim3(256), 0, st, z, t, onehot, c, C, hw, n, child, mask_pred);
   else hipLaunchKernelGGL((predict_metrics_kernel<16>), grid, dim3(256), 0, st, z, t, onehot, c, C, hw, n, child, mask_pred);
   HRSEG_LAUNCH_CHECK("predict_metrics");
+  return 0;
+}
+
+extern "C" int hrseg_consistency_bwd(const float* p, const float* pprev, const float* g, float scale, float* dp,
+                                     float* dpprev, int B, int C, int Cprev, long hw, int ngroups,
+                                     const int* group_parent, const int* group_size, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(p && pprev && g && dp && dpprev && B > 0 && C > 0 && C <= MAXC && Cprev > 0 && Cprev <= MAXC &&
+                      hw > 0 && ngroups > 0,
+                  "hrseg_consistency_bwd: bad arguments");
+  Groups gr;
+  if (int e = fill_groups(gr, ngroups, group_parent, group_size, C, Cprev, "hrseg_consistency_bwd")) return e;
+  const long n = (long)B * hw;
+  hipLaunchKernelGGL(consistency_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, p, pprev, g,
+                     scale, dp, dpprev, C, Cprev, hw, n, gr);
+  HRSEG_LAUNCH_CHECK("consistency_bwd");
   return 0;
 }

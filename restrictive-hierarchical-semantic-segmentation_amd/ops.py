@@ -470,6 +470,16 @@ def consistency_sums(p, pprev, group_parent, group_size):
     return out
 
 
+def consistency_bwd(p, pprev, g, scale, group_parent, group_size):
+    """-> (dp, dpprev) for  scale * g * sum |sum_children P - P_parent|"""
+    p, pprev = _c(p), _c(pprev)
+    B, Cn, H, W = p.shape
+    dp, dpprev = torch.empty_like(p), torch.empty_like(pprev)
+    call("hrseg_consistency_bwd", ptr(p), ptr(pprev), ptr(g), float(scale), ptr(dp), ptr(dpprev), B, Cn, pprev.shape[1],
+         H * W, len(group_parent), _lib.int_array(group_parent), _lib.int_array(group_size))
+    return dp, dpprev
+
+
 def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):
     """-> (onehot or None, confusion matrix [K,K] int64 with K = C + child)"""
     z, t = _c(z), _c(t)

@@ -169,3 +169,72 @@ def test_graphed_train_step_tracks_eager():
     for a, b in zip(got, eager[1:]):
         assert abs(a - b) < 2e-3 * abs(b), (got, eager)
     assert opt.state_dict()["step"] == 4
+
+
+def test_consistency_on_model_probabilities_is_differentiable():
+    """gradient through probs_per_level (composition + FiLM chain) against the oracle's autograd"""
+    from oracle import models as OM
+    from oracle import losses as OL
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    kind, hier, tree_file, size, batch = CASES["unet_hier_ext_32"]
+    g = load_golden("unet_hier_ext_32")
+    tree = load_tree(tree_file)
+    x = torch.from_numpy(g["x"])
+    om = build_model(OM, kind, hier, tree, size)
+    om.train()
+    probs, _ = om(x, type=1)
+    lo = OL.hierarchical_consistency_loss(probs, om.levels, om.parent_of) + sum((p * p).mean() for p in probs)
+    lo.backward()
+    pm = build_model(PM, kind, hier, tree, size).cuda()
+    pm.train()
+    pprobs, _ = pm(x.cuda(), type=1)
+    lp = PL.hierarchical_consistency_loss(pprobs, pm.levels, pm.parent_of) + sum((p * p).mean() for p in pprobs)
+    assert abs(float(lp) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
+    lp.backward()
+    og = dict(om.named_parameters())
+    checked = 0
+    for n, p in pm.named_parameters():
+        if n.split(".")[0] in ("heads", "films"):
+            ref = og[n].grad
+            assert float((p.grad.cpu() - ref).abs().max()) < 5e-3 * float(ref.abs().max()) + 1e-7, n
+            checked += 1
+    assert checked >= 8
+
+
+def test_train_epoch_and_test_loops_run():
+    """the reference-shaped loops (train.py:161-393) on a synthetic loader"""
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd.Metrics import performance_metrics as PP
+    from hrseg_amd import train as PT
+    from hrseg_amd.utils.hierarchy import get_classes
+    tree = load_tree("class_tree_tl.json")
+    nc = get_classes(tree, full=True)
+    weights = level_weights_for("class_tree_tl.json", True)
+    args = _args("unet", True, nc, weights, 2)
+    model = build_model(PM, "unet", True, tree, 32).cuda()
+    opt = PT.FusedAdamW(model, lr=[1e-4])
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in nc]
+    loader = PT.synthetic_loader(tree, 6, 32, 2, hierarchical=True, seed=1)
+    mets = [PP.Accuracy(), PP.Jaccardindex(), PP.DiceScore(), PP.Precision(), PP.Recall()]
+    out = PT.train_epoch(model, torch.device("cuda"), loader, opt, 1, fns, args, tree, None, *mets, epoch_num=1)
+    loss, cls, acc, iou, dice, prec, rec, lvl = out
+    assert np.isfinite(loss) and len(cls) == sum(nc) and 0 <= iou <= 1 and len(lvl) == 2
+    res = PT.test(model, torch.device("cuda"), loader, 1, *mets, args, None, fns, tree, None)
+    assert np.isfinite(res[0]) and len(res[2]) == sum(nc) and np.isfinite(res[-1])
+    # the API-compatible get_metrics with the five metric objects agrees with the fused counts
+    x, t = next(iter(loader))
+    model.eval()
+    with torch.no_grad():
+        probs, logits = model(x.cuda(), type=1)
+    targets = PT.split_targets(t.cuda(), args)
+    acc_l, iou_l, dice_l, prec_l, rec_l = [], [], [], [], []
+    cm = PT._new_class_metrics(sum(nc))
+    PT.get_metrics(probs, targets, acc_l, iou_l, dice_l, prec_l, rec_l, mets[0], mets[1], mets[2], mets[3], mets[4],
+                   torch.device("cuda"), cm, args)
+    from hrseg_amd import ops
+    cms = [ops.predict_metrics(p, tt, child=(L > 0), mask_pred=False, want_onehot=False)[1]
+           for L, (p, tt) in enumerate(zip(probs, targets))]
+    vec = PT._metric_vectors(cms)
+    assert abs(iou_l[0] - float(vec["iou"].mean())) < 1e-6
