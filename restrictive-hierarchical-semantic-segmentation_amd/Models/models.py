@@ -141,6 +141,12 @@ class _Run:
             hook = m._grad_hook if (L == 0) else None
             lv["rec"].backward(hook)
             lv.clear()
+        # weight gradients ran on the side stream: everything after the reverse pass (all-reduce tail,
+        # optimizer) is ordered behind them
+        from ..engine import wgrad_stream
+        side = wgrad_stream(flat.grad.device)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         flat.attach_grads()
         if m._grad_hook is not None:
             m._grad_hook("end")

@@ -15,9 +15,26 @@ in-place accumulation is always safe.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
+
+# Weight gradients are off the critical path of the reverse pass (nothing reads them before the
+# all-reduce / optimizer), so they run on a second HIP stream next to the data-gradient + BN chain:
+# their MFMA work fills the time the chain spends in bandwidth-bound kernels.  HRSEG_WGRAD_STREAM=0
+# keeps everything on one stream.
+_SIDE = {}
+
+
+def wgrad_stream(device):
+    if os.environ.get("HRSEG_WGRAD_STREAM", "1") == "0":
+        return None
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class Act:
@@ -130,6 +147,7 @@ class Recorder:
         self.tape = []
         self.flat = flat
         self.wt_cache = {}
+        self.used_side = False
 
     # ------------------------------------------------------------------ helpers
     def _push(self, fn):
@@ -215,9 +233,24 @@ class Recorder:
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc))
             dys = ops.bn_bwd_group(bw, eval_mode)
             need = [i for i, x in enumerate(xs) if x.needs_grad]
+            side = wgrad_stream(dys[0].device)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    if n == 1:
+                        ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s)
+                    else:
+                        ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items],
+                                             k, s)
+                for t in dys:
+                    t.record_stream(side)     # not reused before the side stream is done reading it
+                for x in xs:
+                    x.data.record_stream(side)
+                self.used_side = True
             if n == 1:
                 conv = items[0][1]
-                ops.conv_wgrad(xs[0].data, dys[0], conv.weight._hr_gstore, k, s)
+                if side is None:
+                    ops.conv_wgrad(xs[0].data, dys[0], conv.weight._hr_gstore, k, s)
                 if need:
                     x = xs[0]
                     if x.grad is None:
@@ -225,7 +258,8 @@ class Recorder:
                     else:
                         ops.conv_dgrad(dys[0], self._wt(conv), x.data.shape, k, s, out=x.grad, accumulate=True)
                 return
-            ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
+            if side is None:
+                ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
             if need:
                 got = ops.conv_dgrad_group([dys[i] for i in need], [self._wt(items[i][1]) for i in need],
                                            [xs[i].data.shape for i in need], k, s, [xs[i].grad for i in need],

@@ -82,6 +82,10 @@ class GradSync:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=chunk.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(chunk.device))
+            from .engine import wgrad_stream
+            side = wgrad_stream(chunk.device)
+            if side is not None:                 # the bucket's weight gradients come from the side stream
+                self._comm_stream.wait_stream(side)
             with torch.cuda.stream(self._comm_stream):
                 self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
