@@ -177,7 +177,7 @@ def main():
     torch.cuda.set_device(device)
     tree, model, ns, loss_fns, opt = build(args, device)
     sync = None
-    if world > 1:
+    if world > 1 or os.environ.get("HRSEG_FORCE_SYNC", "0") == "1":
         sync = GradSync(model)
         opt.grad_scale = 1.0 / world
     hier = not args.flat

@@ -43,8 +43,15 @@ class GradSync:
         self.model = model
         self.group = group
         self.marks = marks
+        import os as _os
+        if "HRSEG_SYNC_MIN_BUCKET" in _os.environ:        # elements; a huge value = one all-reduce at the end
+            min_bucket = int(_os.environ["HRSEG_SYNC_MIN_BUCKET"])
         self.min_bucket = min_bucket
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # HRSEG_FORCE_SYNC=1: issue the collectives even on a single rank (rehearses the RCCL + stream
+        # choreography on a one-GPU box)
+        import os
+        self.force = os.environ.get("HRSEG_FORCE_SYNC", "0") == "1" and dist.is_initialized()
         self._comm_stream = None
         self._handles = []
         self._boundary = None
@@ -75,7 +82,7 @@ class GradSync:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         chunk = flat.grad[lo:hi]
         if chunk.is_cuda:
@@ -110,10 +117,14 @@ def init_distributed():
     backend = os.environ.get("HRSEG_DIST_BACKEND", "nccl")
     if "HRSEG_FORCE_DEVICE" in os.environ:
         local = int(os.environ["HRSEG_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("HRSEG_FORCE_SYNC", "0") == "1"
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if (world > 1 or force) and not dist.is_initialized():
         torch.cuda.set_device(local)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
