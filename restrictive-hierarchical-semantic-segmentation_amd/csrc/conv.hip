@@ -35,7 +35,35 @@ struct IgemmArgs {
   unsigned long long offy_pk, offx_pk, wtap_pk;  // 4 bits per tap: off+8, off+8, weight tap
   int T;                     // taps stored per weight row (1 or 9)
   int accumulate;            // y += result
+  float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
+  int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
 };
+
+// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction)
+__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+// Global -> register staging goes through BUFFER loads (resource descriptor in SGPRs + one 32-bit
+// byte offset per lane) instead of flat global loads with 64-bit per-lane addresses: measured on
+// MI355X every vector-memory instruction issued next to an MFMA stream costs matrix-pipe time
+// (tools/ubench/mfma_vmem.hip: 6 global loads per 24 MFMAs 140 -> 103 TFLOP/s, as buffer loads
+// 115), and the conv kernels gain 10-13 % (tools/ubench/depth_lab.hip).  The descriptor's range
+// check also gives the zero padding for free: a lane outside the image uses offset 0xFFFFFFFF.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define HRSEG_BUF_FLAGS 0x00020000      // raw buffer, 32-bit data format (gfx9 family word 3)
+#define HRSEG_BUF_OOB 0xFFFFFFFFu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                           (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), HRSEG_BUF_FLAGS);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff_bytes, 0));
+}
 
 // swizzle of the 16-byte slot inside a 64-byte LDS row so that every 16-lane
 // group of a ds_read_b128 fragment read hits 16 distinct slots of the bank row
@@ -68,6 +96,14 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
   const int s_hi = min(s_lo + per, nstages_all);
   const int nstages = s_hi - s_lo;
 
+  // buffer resources: the input is addressed relative to the first image this tile touches, so the
+  // 32-bit lane offsets only have to span the tile's own images (host-checked), not the tensor
+  const int hw = p.Ho * p.Wo;
+  const int b0 = m0 / hw;
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc(p.x + (size_t)b0 * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b0) * p.Hi * p.Wi * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (size_t)p.N * p.T * p.K * 4);
+
   // rows this thread stages: r = (tid>>2) + 64*i, 16-byte slot q = tid&3
   const int q = tid & 3;
   int rpix[A_ROWS], riy[A_ROWS], rix[A_ROWS];
@@ -75,10 +111,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
   for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + (tid >> 2) + 64 * i;
     if (m < p.M) {
-      const int b = m / (p.Ho * p.Wo);
-      const int rem = m - b * (p.Ho * p.Wo);
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      rpix[i] = b * p.Hi * p.Wi;
+      const int b = fdiv(m, hw, p.rcp_hw);
+      const int rem = m - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      rpix[i] = (b - b0) * p.Hi * p.Wi;
       riy[i] = oy * p.sy;
       rix[i] = ox * p.sx;
     } else {
@@ -106,9 +142,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
 
   // current tap / chunk
   int t = s_lo / kchunks, c = s_lo - t * kchunks;
-  const float* aptr[A_ROWS];
-  bool aok[A_ROWS];
-  const float* bptr[B_LOADS];
+  unsigned aoff[A_ROWS], boff[B_LOADS];   // byte offsets into rx / rw; HRSEG_BUF_OOB reads zeros
   auto set_tap = [&](int tap) {
     const int oy = (int)((p.offy_pk >> (4 * tap)) & 15) - 8;
     const int ox = (int)((p.offx_pk >> (4 * tap)) & 15) - 8;
@@ -116,11 +150,14 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
       const int iy = riy[i] + oy, ix = rix[i] + ox;
-      aok[i] = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
-      aptr[i] = p.x + (size_t)(aok[i] ? (rpix[i] + iy * p.Wi + ix) : 0) * p.ldx + 4 * q;
+      const bool ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      aoff[i] = ok ? ((unsigned)(rpix[i] + iy * p.Wi + ix) * (unsigned)p.ldx + 4u * q) * 4u : HRSEG_BUF_OOB;
     }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) bptr[i] = p.w + ((size_t)(n0 + b_row[i]) * p.T + wt) * p.K + b_col[i];
+    for (int i = 0; i < B_LOADS; ++i)
+      boff[i] = (tid + 256 * i < B_F4)
+                    ? ((unsigned)((n0 + b_row[i]) * p.T + wt) * (unsigned)p.K + (unsigned)b_col[i]) * 4u
+                    : HRSEG_BUF_OOB;
   };
 
   f32x4 ra[A_ROWS][KC], rb[B_LOADS];
@@ -129,17 +166,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i)
 #pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (aok[i]) v = *reinterpret_cast<const f32x4*>(aptr[i] + c0 + 16 * j);
-        ra[i][j] = v;
-      }
+      for (int j = 0; j < KC; ++j) ra[i][j] = buf_load4(rx, aoff[i], (c0 + 16 * j) * 4);
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (tid + 256 * i < B_F4) v = *reinterpret_cast<const f32x4*>(bptr[i] + c0);
-      rb[i] = v;
-    }
+    for (int i = 0; i < B_LOADS; ++i) rb[i] = buf_load4(rw, boff[i], c0 * 4);
     if (++c == kchunks) {
       c = 0;
       ++t;
@@ -213,10 +242,13 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
   for (int m = 0; m < WTM; ++m) {
     const int row = m0 + wave * 16 * WTM + 16 * m + (lane & 15);
     if (row >= p.M) continue;
-    const int b = row / (p.Ho * p.Wo);
-    const int rem = row - b * (p.Ho * p.Wo);
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    const size_t pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
+    size_t pix = row;
+    if (!p.direct_out) {
+      const int b = fdiv(row, hw, p.rcp_hw);
+      const int rem = row - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
+    }
     float* yrow = p.y + pix * p.ldy;
 #pragma unroll
     for (int n = 0; n < WTN; ++n) {
@@ -325,7 +357,25 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
   return pl;
 }
 
-static int dispatch_igemm(const IgemmArgs& a, hipStream_t st) {
+// derived fields + the host-side check behind the kernels' 32-bit buffer offsets: a tile (<= 256 GEMM
+// rows) touches at most ceil(256 / (Ho*Wo)) + 1 consecutive images, which must span < 4 GB
+static int finalize_args(IgemmArgs& a) {
+  a.rcp_hw = 1.0f / (float)(a.Ho * a.Wo);
+  a.rcp_w = 1.0f / (float)a.Wo;
+  a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
+  const double span = ((double)ceil_div(256, a.Ho * a.Wo) + 1.0) * a.Hi * a.Wi * (double)a.ldx * 4.0;
+  const double wbytes = (double)a.N * a.T * a.K * 4.0;
+  if (span >= 4294967296.0 || wbytes >= 4294967296.0) {
+    hrseg_set_error("igemm: image of %dx%dx%d floats (or %g-byte weight) exceeds the 4 GB buffer-offset range",
+                    a.Hi, a.Wi, a.ldx, wbytes);
+    return HRSEG_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
+static int dispatch_igemm(const IgemmArgs& a_in, hipStream_t st) {
+  IgemmArgs a = a_in;
+  if (int e = finalize_args(a)) return e;
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
 #define IG4(M_, N_, K_, D_) \
@@ -562,6 +612,7 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
     end += tiles[i] * ks[i];
     g.blk_end[o] = end;
     g.a[o] = a[i];
+    if (finalize_args(g.a[o])) return 1;   // per-problem launches report the error
   }
   if (wtn == 3 && kc == 3) launch_igemm_group<1, 3, 3, 1>(g, st);
   else if (wtn == 3 && kc == 2) launch_igemm_group<1, 3, 2, 1>(g, st);
@@ -671,15 +722,6 @@ struct WgradArgs {
   float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
 };
 
-// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction)
-__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
-  int q = (int)((float)n * rcp);
-  const int r = n - q * d;
-  q += (r >= d) ? 1 : 0;
-  q -= (r < 0) ? 1 : 0;
-  return q;
-}
-
 // Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
 // the stage's pixels (the MFMA k dimension), so each wave accumulates the full TN x TK tile set and
 // the block reduces across waves through LDS before the atomic add.
@@ -706,31 +748,34 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
   const int nstages = (hi - lo + PIX - 1) / PIX;
   const int q = tid & 3, r0 = tid >> 2;
 
+  // buffer resources relative to this block's pixel range (dy) / its first image (x): rows past the
+  // range and padding pixels read zeros through the descriptor's range check
+  const int hw = p.Ho * p.Wo;
+  const int b_lo = lo / hw;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc(p.x + (size_t)b_lo * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b_lo) * p.Hi * p.Wi * p.ldx * 4);
+
   f32x4 ra[ROWS][TN], rb[ROWS][TK];
   auto stage_load = [&](int s) {
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-      const int m = lo + s * PIX + r0 + 64 * i;
+      const int ml = s * PIX + r0 + 64 * i;          // row inside the block's range
+      const int m = lo + ml;
       const bool ok = m < hi;
-      const float* dyp = p.dy + (size_t)(ok ? m : 0) * p.lddy + n0 + 4 * q;
+      const unsigned dyo = ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(dyp + 16 * j);
-        ra[i][j] = v;
-      }
-      const int b = fdiv(m, p.Ho * p.Wo, p.rcp_hw);
-      const int rem = m - b * (p.Ho * p.Wo);
+      for (int j = 0; j < TN; ++j) ra[i][j] = buf_load4(rdy, dyo, 64 * j);
+      const int b = fdiv(m, hw, p.rcp_hw);
+      const int rem = m - b * hw;
       const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
       const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
       const bool okx = ok & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
-      const float* xp = p.x + (size_t)(okx ? ((b * p.Hi + iy) * p.Wi + ix) : 0) * p.ldx + k0 + 4 * q;
+      const unsigned xo =
+          okx ? ((unsigned)(((b - b_lo) * p.Hi + iy) * p.Wi + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u
+              : HRSEG_BUF_OOB;
 #pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (okx) v = *reinterpret_cast<const f32x4*>(xp + 16 * j);
-        rb[i][j] = v;
-      }
+      for (int j = 0; j < TK; ++j) rb[i][j] = buf_load4(rx, xo, 64 * j);
     }
   };
   auto stage_store = [&](int buf) {
@@ -850,16 +895,28 @@ extern "C" int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks) {
   return 0;
 }
 
+// host-side check behind the 32-bit buffer offsets of wgrad_body: one block's pixel range
+static int check_wgrad_span(const WgradArgs& a) {
+  const double imgs = (double)ceil_div(a.pix_per_block, a.Ho * a.Wo) + 1.0;
+  if (imgs * a.Hi * a.Wi * (double)a.ldx * 4.0 >= 4294967296.0 || (double)a.pix_per_block * a.lddy * 4.0 >= 4294967296.0) {
+    hrseg_set_error("wgrad: a block's pixel range (%d pixels) exceeds the 4 GB buffer-offset range", a.pix_per_block);
+    return HRSEG_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
 template <int TN, int TK, int PIX, int DB>
-static void launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
+static int launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
   const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
   int ksplit = target_blocks / tiles;
   if (ksplit < 1) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
   if (ppb < 4 * PIX) ppb = 4 * PIX;
   a.pix_per_block = ppb;
+  if (int e = check_wgrad_span(a)) return e;
   const int gx = ceil_div(a.M, ppb);
   hipLaunchKernelGGL((wgrad_kernel<TN, TK, PIX, DB>), dim3(gx, tiles), dim3(256), 0, st, a);
+  return 0;
 }
 
 template <int TN, int TK>
@@ -873,11 +930,10 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   if (g_tune_wg_pix) pix = g_tune_wg_pix;
   if (g_tune_wg_db) db = g_tune_wg_db;
   if (g_tune_wg_blocks) target = g_tune_wg_blocks;
-  if (pix == 64 && db == 1) launch_wgrad_cfg<TN, TK, 64, 1>(a, target, st);
-  else if (pix == 64) launch_wgrad_cfg<TN, TK, 64, 2>(a, target, st);
-  else if (db == 1) launch_wgrad_cfg<TN, TK, 128, 1>(a, target, st);
-  else launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
-  return 0;
+  if (pix == 64 && db == 1) return launch_wgrad_cfg<TN, TK, 64, 1>(a, target, st);
+  if (pix == 64) return launch_wgrad_cfg<TN, TK, 64, 2>(a, target, st);
+  if (db == 1) return launch_wgrad_cfg<TN, TK, 128, 1>(a, target, st);
+  return launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
 }
 
 static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
@@ -906,6 +962,7 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
     if (a[i].Cout % (16 * tn) || a[i].Cin % (16 * tk)) return 1;
     int gx, tiles;
     plan_wgrad_blocks(a[i], tn, tk, 64, gx, tiles);
+    if (check_wgrad_span(a[i])) return 1;   // the per-problem launch reports the error
     g.gx[i] = gx;
     end += gx * tiles;
     g.blk_end[i] = end;
@@ -1208,7 +1265,7 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   a.rcp_w = 1.0f / (float)s->Wo;
   const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
   const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
-#define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { launch_wgrad<TN_, TK_>(a, st); }
+#define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { if (int e = launch_wgrad<TN_, TK_>(a, st)) return e; }
   WG(1, 1) WG(1, 2) WG(1, 3) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 3) WG(2, 4)
   WG(3, 1) WG(3, 2) WG(3, 3) WG(3, 4) WG(4, 1) WG(4, 2) WG(4, 3) WG(4, 4)
 #undef WG
