@@ -674,31 +674,70 @@ __global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* 
                                                                    float* __restrict__ dw, int B, int Hi,
                                                                    int Wi, int Cin, int Ho, int Wo, int Cout,
                                                                    int ks, int stride, int pix_per_block) {
+  // Block = 64 output channels x a pixel range, walked in 64-pixel stages through LDS: all 256
+  // threads stage the dy tile [64 pix][64 co] and the gathered input taps [64 pix][T][4] with
+  // independent loads (memory-level parallelism instead of a serial per-pixel loop), then thread
+  // (co, tap group tg: taps tg, tg+4, tg+8) runs the 64-pixel FMA loop out of LDS (dy: conflict-free,
+  // x: broadcast).  One atomic per weight per block; the grid keeps blocks x weights small.
+  constexpr int P = 64;
+  __shared__ __attribute__((aligned(16))) float dys[P][64];
+  __shared__ __attribute__((aligned(16))) float xs[P][12][4];
   const int T = ks * ks, pad = (ks - 1) / 2;
-  const int co = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int tg = threadIdx.x >> 6;  // taps tg, tg+4, tg+8
-  const long M = (long)B * Ho * Wo;
-  const long lo = (long)blockIdx.x * pix_per_block;
-  const long hi = (lo + pix_per_block < M) ? lo + pix_per_block : M;
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * 64, co = co0 + (tid & 63);
+  const int tg = tid >> 6;
+  const int M = B * Ho * Wo, hw = Ho * Wo;
+  const int lo = blockIdx.x * pix_per_block;
+  const int hi = min(lo + pix_per_block, M);
   float acc[3][4];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
-  for (long m = lo; m < hi; ++m) {
-    const int b = (int)(m / ((long)Ho * Wo));
-    const int rem = (int)(m - (long)b * Ho * Wo);
-    const int oy = rem / Wo, ox = rem - oy * Wo;
-    const float g = (co < Cout) ? dy[(size_t)m * lddy + co] : 0.f;
+  for (int s0 = lo; s0 < hi; s0 += P) {
+    // dy tile: thread -> (pixel j>>4, 4 channels (j&15)*4)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int t = tg + 4 * a;
-      if (t >= T) continue;
-      const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
-      if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-      const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
-      for (int c = 0; c < Cin; ++c) acc[a][c] = fmaf(g, xp[c], acc[a][c]);
+    for (int r = 0; r < (P * 16) / 256; ++r) {
+      const int j = tid + 256 * r;
+      const int pp = j >> 4, c4 = (j & 15) * 4;
+      const int m = s0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) {
+        const float* src = dy + (size_t)m * lddy + co0 + c4;
+        if (co0 + c4 + 3 < Cout && (lddy & 3) == 0) v = *reinterpret_cast<const f32x4*>(src);
+        else
+          for (int e = 0; e < 4; ++e) if (co0 + c4 + e < Cout) v[e] = src[e];
+      }
+      *reinterpret_cast<f32x4*>(&dys[pp][c4]) = v;
     }
+    // input taps: item -> (pixel, tap)
+    for (int j = tid; j < P * T; j += 256) {
+      const int pp = j / T, t = j - pp * T;
+      const int m = s0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) {
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+          const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
+          for (int c = 0; c < Cin; ++c) v[c] = xp[c];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&xs[pp][t][0]) = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int pp = 0; pp < P; ++pp) {
+      const float g = dys[pp][tid & 63];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[pp][tg + 4 * a][0]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(g, xv[c], acc[a][c]);
+      }
+    }
+    __syncthreads();
   }
   if (co >= Cout) return;
 #pragma unroll
@@ -1247,7 +1286,10 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   const int T = s->ksize * s->ksize;
   if (s->Cin <= 4) {
     const long M = (long)s->B * s->Ho * s->Wo;
-    const int ppb = 64;   // many short pixel ranges: the per-thread loop is latency-bound
+    // ~512 blocks (measured, tools/misc_bench.py): every block adds into the same Cout*T*Cin
+    // addresses, ~0.35 us of serialized atomics per block; fewer blocks leave CUs idle
+    const int nblk_target = g_tune_wg_blocks ? g_tune_wg_blocks : 512;
+    int ppb = (int)ceil_div(ceil_div(M, nblk_target), 64) * 64;
     dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
     hipLaunchKernelGGL(conv_small_cin_wgrad_kernel, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi,
                        s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, ppb);
