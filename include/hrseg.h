@@ -142,7 +142,8 @@ typedef struct {
 } hrseg_bn_fwd_t;
 int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
 typedef struct {
-  const float* dz; int lddz; const float* z; int ldz; int relu;
+  const float* dz; int lddz; const float* z; int ldz; int relu;   /* relu with z == NULL: the forward had
+                                                        no residual, the mask is recomputed from y    */
   const float* y; int ldy; const float* coef;
   float* dgamma; float* dbeta;                       /* += (may be NULL)                            */
   float* dy; int lddy;                               /* out (may alias dz)                          */

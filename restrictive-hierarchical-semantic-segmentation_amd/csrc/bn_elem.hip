@@ -32,6 +32,14 @@ static int elem_grid(long npix, int C) {
   for (long pix = (long)blockIdx.x * (L).P + (L).pl; pix < (npix); pix += (long)gridDim.x * (L).P)
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// y*scale + shift with ONE rounding per element: the forward pass and the backward pass's recomputed
+// ReLU mask must evaluate the identical expression
+__device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 sc, f32x4 sh) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(y[j], sc[j], sh[j]);
+  return v;
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // C > 1024 is not supported by the quad mapping (Q must be <= 256): the widest
@@ -539,7 +547,10 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 // =========================================================================== grouped batch norm
 // n independent BatchNorm problems (the parallel HRNet branches, or just one) per launch: block
 // ranges [blk_end[g-1], blk_end[g]) belong to problem g.  Three launches forward (statistics,
-// finalize, apply) and three backward (reduce, finalize, apply) whatever n is.
+// finalize, apply) and three backward (reduce, finalize, apply) whatever n is.  (Folding the finalize
+// into the statistics kernel -- last block to finish reduces the partials -- was measured 2-3x SLOWER:
+// one block reading up to 600 KB of cold partials takes 30-60 us against 7 us for the C/16-block
+// finalize launch, and a device-scope fence per block costs L2 write-backs.)
 #define BN_MAXG 4
 struct BnGroupHdr { int n; int blk_end[BN_MAXG]; };
 __device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nblk) {
@@ -565,10 +576,12 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
   const long hi = (lo + per < npix) ? lo + per : npix;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (L.active) {
-    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f}, sc = mean, sh = mean;
     if (bwd) {
       mean = ld4(coef + 4 * L.cq);
       rstd = ld4(coef + C + 4 * L.cq);
+      sc = ld4(coef + 2 * C + 4 * L.cq);
+      sh = ld4(coef + 3 * C + 4 * L.cq);
     }
     for (long pix = lo + L.pl; pix < hi; pix += L.P) {
       f32x4 v = ld4(a0 + pix * ld0 + 4 * L.cq);
@@ -576,12 +589,14 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
         s += v;
         s2 += v * v;
       } else {
+        const f32x4 yv = ld4(yy + pix * ldy + 4 * L.cq);
         if (relu) {
-          const f32x4 zz = ld4(zmask + pix * ldz + 4 * L.cq);
+          // z not given: the forward had no residual, so z > 0 <=> y*scale+shift > 0 (4 bytes less per element)
+          const f32x4 zz = zmask ? ld4(zmask + pix * ldz + 4 * L.cq) : bn_affine(yv, sc, sh);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = zz[j] > 0.f ? v[j] : 0.f;
         }
-        const f32x4 xh = (ld4(yy + pix * ldy + 4 * L.cq) - mean) * rstd;
+        const f32x4 xh = (yv - mean) * rstd;
         s += v;
         s2 += v * xh;
       }
@@ -658,7 +673,7 @@ __global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
   if (!L.active) return;
   const f32x4 sc = ld4(p.coef + 2 * C + 4 * L.cq), sh = ld4(p.coef + 3 * C + 4 * L.cq);
   for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
-    f32x4 v = ld4(p.y + pix * p.ldy + 4 * L.cq) * sc + sh;
+    f32x4 v = bn_affine(ld4(p.y + pix * p.ldy + 4 * L.cq), sc, sh);
     if (p.residual) v += ld4(p.residual + pix * p.ldr + 4 * L.cq);
     if (p.relu) {
 #pragma unroll
@@ -698,6 +713,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
   if (!L.active) return;
   const double* totals = p.partial + (size_t)p.nchunks * 2 * C;
   const f32x4 mean = ld4(p.coef + 4 * L.cq), rstd = ld4(p.coef + C + 4 * L.cq), scale = ld4(p.coef + 2 * C + 4 * L.cq);
+  const f32x4 shift = ld4(p.coef + 3 * C + 4 * L.cq);
   f32x4 mg, mgx;
   const float inv = eval_mode ? 0.f : (float)(1.0 / (double)p.npix);
 #pragma unroll
@@ -707,12 +723,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
   }
   for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
     f32x4 gg = ld4(p.dz + pix * p.lddz + 4 * L.cq);
+    const f32x4 yv = ld4(p.y + pix * p.ldy + 4 * L.cq);
     if (p.relu) {
-      const f32x4 zz = ld4(p.z + pix * p.ldz + 4 * L.cq);
+      const f32x4 zz = p.z ? ld4(p.z + pix * p.ldz + 4 * L.cq) : bn_affine(yv, scale, shift);
 #pragma unroll
       for (int j = 0; j < 4; ++j) gg[j] = zz[j] > 0.f ? gg[j] : 0.f;
     }
-    const f32x4 xh = (ld4(p.y + pix * p.ldy + 4 * L.cq) - mean) * rstd;
+    const f32x4 xh = (yv - mean) * rstd;
     st4(p.dy + pix * p.lddy + 4 * L.cq, scale * (gg - mg - xh * mgx));
     if (p.dres) {
       float* d = p.dres + pix * p.lddres + 4 * L.cq;
@@ -992,7 +1009,7 @@ extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_m
   for (int i = 0; i < n; ++i) {
     const hrseg_bn_bwd_t& p = probs[i];
     if (int e = check_c(p.C, "hrseg_bn_bwd_group")) return e;
-    HRSEG_CHECK_ARG(p.dz && p.y && p.coef && p.dy && p.partial && (!p.relu || p.z) && p.npix > 0 && p.nchunks > 0,
+    HRSEG_CHECK_ARG(p.dz && p.y && p.coef && p.dy && p.partial && p.npix > 0 && p.nchunks > 0,
                     "hrseg_bn_bwd_group: bad arguments");
     g.p[i] = p;
   }

@@ -229,7 +229,9 @@ class Recorder:
                     else:
                         dres_acc = True
                     dres = res.grad
-                bw.append(dict(dz=dz, z=z.data, relu=relu, y=y, coef=coef, dgamma=bn.weight._hr_gstore,
+                # without a residual the ReLU mask is recomputed from y: the backward never reads z
+                bw.append(dict(dz=dz, z=z.data if (relu and res is not None) else None, relu=relu, y=y, coef=coef,
+                               dgamma=bn.weight._hr_gstore,
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc))
             dys = ops.bn_bwd_group(bw, eval_mode)
             need = [i for i, x in enumerate(xs) if x.needs_grad]

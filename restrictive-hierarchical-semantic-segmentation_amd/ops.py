@@ -243,7 +243,8 @@ def bn_bwd_group(items, eval_mode):
         keep.append(part)
         dres = it.get("dres")
         a.dz, a.lddz = ptr(dz), _ld(dz)
-        a.z, a.ldz, a.relu = (ptr(z) if it["relu"] else None), (_ld(z) if it["relu"] else 0), int(it["relu"])
+        use_z = it["relu"] and z is not None      # z None: mask recomputed from y (forward without residual)
+        a.z, a.ldz, a.relu = (ptr(z) if use_z else None), (_ld(z) if use_z else 0), int(it["relu"])
         a.y, a.ldy, a.coef = ptr(y), _ld(y), ptr(it["coef"])
         a.dgamma, a.dbeta = ptr(it["dgamma"]), ptr(it["dbeta"])
         a.dy, a.lddy = ptr(dz), _ld(dz)

@@ -132,6 +132,53 @@ def test_batchnorm_eval_coef(ops):
     assert rel(nchw(z), F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)) < 1e-5
 
 
+def test_batchnorm_group_fwd_bwd(ops):
+    """grouped BN (statistics, finalize, apply; reduce, totals, apply): four problems of different size per
+    launch, run twice, with and without residual; without residual the backward gets no z and recomputes
+    the ReLU mask from y"""
+    cfgs = [(48, 37, 41, 2, True), (96, 19, 20, 2, False), (384, 5, 6, 2, False), (192, 9, 9, 3, True)]
+    g = torch.Generator().manual_seed(7)
+    probs = []
+    for C, H, W, B, res in cfgs:
+        y = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+        r = torch.randn(B, C, H, W, generator=g) if res else None
+        dz = torch.randn(B, C, H, W, generator=g)
+        probs.append((y, gamma, beta, r, dz))
+    for rep in range(2):
+        refs, items = [], []
+        for y, gamma, beta, r, dz in probs:
+            C = y.shape[1]
+            yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            rr = r.clone().requires_grad_(True) if r is not None else None
+            rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+            z_ref = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+            if rr is not None:
+                z_ref = z_ref + rr
+            z_ref = F.relu(z_ref)
+            z_ref.backward(dz)
+            refs.append((z_ref.detach(), yr.grad, gr.grad, br.grad, rr.grad if rr is not None else None, rm_ref, rv_ref))
+            items.append(dict(y=nhwc(y), gamma=gamma.cuda(), beta=beta.cuda(), rm=torch.zeros(C, device="cuda"),
+                              rv=torch.ones(C, device="cuda"), nbt=torch.zeros((), dtype=torch.int64, device="cuda"),
+                              momentum=0.1, eps=1e-5, residual=nhwc(r) if r is not None else None, relu=True))
+        zc = ops.bn_fwd_group(items, True)
+        bw = []
+        for (y, gamma, beta, r, dz), it, (z, coef), ref in zip(probs, items, zc, refs):
+            assert rel(nchw(z), ref[0]) < 1e-5
+            assert rel(it["rm"], ref[5]) < 1e-5 and rel(it["rv"], ref[6]) < 1e-5 and int(it["nbt"]) == 1
+            C = y.shape[1]
+            bw.append(dict(dz=nhwc(dz), z=z if r is not None else None, relu=True, y=it["y"], coef=coef,
+                           dgamma=torch.zeros(C, device="cuda"), dbeta=torch.zeros(C, device="cuda"),
+                           dres=torch.empty_like(it["y"]) if r is not None else None, dres_accumulate=False))
+        dys = ops.bn_bwd_group(bw, False)
+        for b, dy, ref in zip(bw, dys, refs):
+            scale = max(float(ref[1].abs().max()), 1.0)
+            assert float((nchw(dy) - ref[1]).abs().max()) < 2e-5 * scale
+            assert rel(b["dgamma"], ref[2]) < 2e-5 and rel(b["dbeta"], ref[3]) < 2e-5
+            if ref[4] is not None:
+                assert rel(nchw(b["dres"]), ref[4]) < 1e-6
+
+
 @pytest.mark.parametrize("H,W", [(20, 20), (31, 17), (5, 8)])
 def test_maxpool(ops, H, W):
     g = torch.Generator().manual_seed(H)
