@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--host-time", action="store_true", help="also log the host-side issue time of one step")
     return ap.parse_args()
 
 
@@ -224,6 +225,14 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     final_loss = float(loss)
+    if args.host_time:
+        for _ in range(2):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            step()
+            t_issue = time.perf_counter() - th
+            torch.cuda.synchronize()
+            log("host issue %.1f ms, step complete after %.1f ms" % (1e3 * t_issue, 1e3 * (time.perf_counter() - th)))
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))

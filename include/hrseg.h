@@ -270,6 +270,16 @@ int hrseg_adamw_dev(float* p, const float* g, float* m, float* v, long n, const 
                     float* state, hrseg_stream_t stream);
 int hrseg_fill(float* p, float v, long n, hrseg_stream_t stream);
 
+/* ------------------------------------------------------------------ target encoding (input side of the path)
+ * SegDataset.separate_masks / traverse_tree / process_ignore_values (Data/dataset.py:41-124,
+ * 227-265): label image [B,hw] of uint8 pixel values -> out [B,C,hw] fp32 (NCHW planes).
+ * on_lut: DEVICE table [256] of uint64, bit c set when channel c's node contains the leaf class
+ * with that pixel value; parent: HOST array [C], channel index of the node's direct parent or -1
+ * (roots, and every channel in flat mode).  Channel value: 1 on the node, else 0 for roots / inside
+ * the parent's area, else -1.  C <= 64. */
+int hrseg_encode_targets(const unsigned char* label, const unsigned long long* on_lut, const int* parent,
+                         float* out, int B, int C, long hw, hrseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

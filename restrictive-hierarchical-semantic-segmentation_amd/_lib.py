@@ -95,6 +95,7 @@ PROTOTYPES = {
     "hrseg_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     "hrseg_adamw_dev": [_p, _p, _p, _p, _l, _p, _p, _p],
     "hrseg_fill": [_p, _f, _l, _p],
+    "hrseg_encode_targets": [_p, _p, C.POINTER(C.c_int), _p, _i, _i, _l, _p],
 }
 
 _lib.hrseg_last_error_string.restype = C.c_char_p

@@ -917,3 +917,51 @@ extern "C" int hrseg_consistency_bwd(const float* p, const float* pprev, const f
   HRSEG_LAUNCH_CHECK("consistency_bwd");
   return 0;
 }
+
+// --------------------------------------------------------------------------- target encoding
+// Label image (one pixel value per leaf class) -> the per-node target planes the losses and
+// metrics consume: SegDataset.separate_masks / traverse_tree / process_ignore_values of the reference
+// (Data/dataset.py:41-124, 227-265) for an identity spatial transform.  on_lut[v] has bit c set when
+// channel c's node contains the leaf whose pixel value is v (a parent = OR of its leaves), so one
+// 8-byte table read per pixel replaces the per-node mask images.  HBM-bound: 1 byte in, 4*C out.
+struct EncodeParents { int parent[64]; };
+__global__ __launch_bounds__(256) void encode_targets_kernel(const unsigned char* __restrict__ label,
+                                                             const unsigned long long* __restrict__ on_lut,
+                                                             EncodeParents pr, float* __restrict__ out, int C,
+                                                             long hw, long n) {
+  __shared__ unsigned long long lut[256];
+  lut[threadIdx.x] = on_lut[threadIdx.x];
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / hw, pix = i - b * hw;
+    const unsigned long long bits = lut[label[i]];
+    float* o = out + (size_t)b * C * hw + pix;
+    for (int c = 0; c < C; ++c) {
+      const int par = pr.parent[c];
+      float v;
+      if ((bits >> c) & 1ull) v = 1.f;
+      else if (par < 0 || ((bits >> par) & 1ull)) v = 0.f;   // root, or inside the direct parent's area
+      else v = -1.f;                                          // outside the parent: ignored by loss and metrics
+      o[(size_t)c * hw] = v;
+    }
+  }
+}
+
+extern "C" int hrseg_encode_targets(const unsigned char* label, const unsigned long long* on_lut,
+                                    const int* parent, float* out, int B, int C, long hw, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(label && on_lut && parent && out && B > 0 && hw > 0, "hrseg_encode_targets: bad arguments");
+  HRSEG_CHECK_ARG(C >= 1 && C <= 64, "hrseg_encode_targets: C=%d not in 1..64", C);
+  EncodeParents pr;
+  for (int c = 0; c < 64; ++c) pr.parent[c] = -1;
+  for (int c = 0; c < C; ++c) {
+    HRSEG_CHECK_ARG(parent[c] >= -1 && parent[c] < C, "hrseg_encode_targets: parent[%d]=%d out of range", c, parent[c]);
+    pr.parent[c] = parent[c];
+  }
+  const long n = (long)B * hw;
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(encode_targets_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, label, on_lut, pr,
+                     out, C, hw, n);
+  HRSEG_LAUNCH_CHECK("encode_targets");
+  return 0;
+}

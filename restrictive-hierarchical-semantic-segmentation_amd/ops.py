@@ -323,6 +323,18 @@ def nhwc_to_nchw(x):
     return out
 
 
+def encode_targets(label, on_lut, parent):
+    """label [B,H,W] uint8 (device), on_lut [256] int64 bit table (device), parent list[int] -> [B,C,H,W] fp32"""
+    assert label.dtype == torch.uint8 and label.is_cuda and label.dim() == 3
+    assert on_lut.dtype == torch.int64 and on_lut.numel() == 256 and on_lut.is_cuda
+    label = label.contiguous()
+    B, H, W = label.shape
+    Cn = len(parent)
+    out = torch.empty((B, Cn, H, W), dtype=torch.float32, device=label.device)
+    call("hrseg_encode_targets", ptr(label), ptr(on_lut), _lib.int_array(list(parent)), ptr(out), B, Cn, H * W)
+    return out
+
+
 def fill(t, v):
     call("hrseg_fill", ptr(t), float(v), t.numel())
     return t
