@@ -205,9 +205,18 @@ class _EngineModel(nn.Module):
             run.levels.append(lv)
             run.logits.append(z)
             return run
+        # The reference re-runs the backbone on the image for every level (D1).  In training that is
+        # faithful work (BN statistics update L times, gradients sum over the passes); in inference
+        # (eval mode, nothing recorded) the L passes are bit-identical, so the features are computed once.
+        shared = None
         for L in range(len(self.levels)):
             rec = Recorder(self.training, record, self._flat)
-            feats = self._backbone(rec, x_nhwc)
+            if shared is None:
+                feats = self._backbone(rec, x_nhwc)
+                if not self.training and not record:
+                    shared = feats
+            else:
+                feats = shared
             film = self.films[L - 1] if L > 0 else None
             z, lv = self._head_forward(rec, feats, self._level_head(L), film, run.probs[L - 1] if L > 0 else None, size)
             groups = None
