@@ -341,8 +341,10 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
   const long blocks = (long)ceil_div(a.M, 64 * pl.wtm) * ntn;
   const int nstages = a.ntaps * (a.K / (16 * pl.kc));
   if (blocks < 256) {
+    // split only long reductions: under ~12 stages per slice the zero fill + atomics cost more than the
+    // idle CUs (tools/conv_sweep.py: 48->384 3x3 s2 @39: 32 us split 3-way, 12 us unsplit)
     pl.ksplit = (int)((448 + blocks - 1) / blocks);
-    if (pl.ksplit > nstages / 3) pl.ksplit = nstages / 3;
+    if (pl.ksplit > nstages / 12) pl.ksplit = nstages / 12;
   }
   if (g_tune_wtm >= 10 && a.N % 96 == 0) pl.wtn = 6;   // tuning: tens digit 1 = 96-channel tiles
   if (g_tune_wtm % 10) pl.wtm = g_tune_wtm % 10;
@@ -594,7 +596,7 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
     const bool can_split = a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1);
     if (can_split && tiles[i] < 512) {
       ks[i] = ceil_div(512, tiles[i]);
-      if (ks[i] > nstages / 3) ks[i] = nstages / 3;
+      if (ks[i] > nstages / 12) ks[i] = nstages / 12;
       if (ks[i] < 1) ks[i] = 1;
     }
     if (ks[i] > 1 && !a[i].accumulate) zero_f32(a[i].y, (size_t)a[i].B * a[i].Hy * a[i].Wy * a[i].N, st);

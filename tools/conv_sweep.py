@@ -15,6 +15,9 @@ SHAPES = [
     ("hr 48->96 3x3s2 @155", 48, 96, 3, 2, 155), ("hr 96->192 3x3s2 @78", 96, 192, 3, 2, 78),
     ("hr 384->48 1x1 @20", 384, 48, 1, 1, 20), ("hr 192->48 1x1 @39", 192, 48, 1, 1, 39),
     ("hr 96->48 1x1 @78", 96, 48, 1, 1, 78),
+    ("hr 256->48 3x3 @155", 256, 48, 3, 1, 155), ("hr 256->96 3x3s2 @155", 256, 96, 3, 2, 155),
+    ("hr 64->64 1x1 @155", 64, 64, 1, 1, 155), ("hr 64->64 3x3s2 @310", 64, 64, 3, 2, 310),
+    ("hr 48->48 3x3s2 @155", 48, 48, 3, 2, 155), ("hr 48->384 3x3s2 @39", 48, 384, 3, 2, 39),
     ("un 64->64 3x3 @620", 64, 64, 3, 1, 620), ("un 256->256 3x3 @155", 256, 256, 3, 1, 155),
     ("un 512->512 3x3 @38", 512, 512, 3, 1, 38), ("un 1024->256 3x3 @77", 1024, 256, 3, 1, 77),
 ]
