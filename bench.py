@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--host-time", action="store_true", help="also log the host-side issue time of one step")
+    ap.add_argument("--no-dedup-line", action="store_true",
+                    help="skip the extra measurement of the opt-in de-duplicated level passes (N=1, hierarchical)")
     return ap.parse_args()
 
 
@@ -271,6 +273,25 @@ def main():
             line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),
                                           "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4)}
         log("timed: %.3f s for %d steps" % (dt, args.steps))
+        if world == 1 and hier and graphed is None and not args.no_dedup_line:
+            # NOT the headline number: the opt-in mode that runs the L bit-identical level passes once
+            # (Models/models.py:_run).  Same result, 1/L of the backbone FLOPs executed -- reported apart.
+            model.dedup_passes = True
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(args.steps):
+                loss_d, _ = step()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            model.dedup_passes = False
+            line["opt_in_dedup_passes"] = {
+                "value": round(args.batch * args.steps / td, 3), "unit": "images/s",
+                "ms_per_step": round(1e3 * td / args.steps, 2), "executed_backbone_passes_per_step": 1,
+                "note": "explicit opt-in (model.dedup_passes / HRSEG_DEDUP_PASSES=1); default and headline value "
+                        "re-execute all L passes as the reference does"}
+            log("opt-in dedup passes: %.1f ms/step" % (1e3 * td / args.steps))
         if not args.no_probe:
             line["roofline"] = probe_dominant_kernel(device, args.batch, args.size)
             log("probe: %s" % json.dumps(line["roofline"]))

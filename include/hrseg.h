@@ -139,6 +139,10 @@ typedef struct {
   float* z; int ldz;
   float* coef;                                       /* out: [4][C] mean, rstd, scale, shift       */
   double* partial; int nchunks;                      /* scratch nchunks*2*C doubles (training)     */
+  int stat_updates;                                  /* training: times the batch statistics enter
+                                                        the running averages / num_batches_tracked
+                                                        (0 or 1 = once; L = de-duplicated level
+                                                        passes, see Models/models.py)               */
 } hrseg_bn_fwd_t;
 int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
 typedef struct {

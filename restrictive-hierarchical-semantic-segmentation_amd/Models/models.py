@@ -14,6 +14,8 @@ engine's reverse pass.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -96,6 +98,7 @@ class _Run:
         self.levels = []        # per level dict
         self.probs, self.logits = [], []
         self.done = False
+        self.shared_tape = False   # de-duplicated passes: every level's head hangs off ONE backbone tape
 
     def backward(self, dprobs, dlogits):
         m = self.model
@@ -133,14 +136,25 @@ class _Run:
                         dp_full[L - 1], dp_own[L - 1], own = prev, True, True
             if dz is None:
                 # nothing flows into this level's logits: its pass contributes no gradient
-                lv["rec"].tape.clear()
+                if not self.shared_tape:
+                    lv["rec"].tape.clear()
                 continue
             dcond = m._head_backward(lv, dz)
             if dcond is not None and L > 0:
                 dp_bcast[L - 1] = dcond if dp_bcast[L - 1] is None else dp_bcast[L - 1] + dcond
+            if self.shared_tape:
+                continue                 # the heads' feature gradients accumulate; one reverse pass below
             hook = m._grad_hook if (L == 0) else None
             lv["rec"].backward(hook)
             lv.clear()
+        if self.shared_tape and n > 0:
+            lv0 = self.levels[0]
+            if lv0["feats"].grad is not None:
+                lv0["rec"].backward(m._grad_hook)
+            else:
+                lv0["rec"].tape.clear()
+            for lv in self.levels:
+                lv.clear()
         # weight gradients ran on the side stream: everything after the reverse pass (all-reduce tail,
         # optimizer) is ordered behind them
         from ..engine import wgrad_stream
@@ -163,6 +177,8 @@ class _EngineModel(nn.Module):
         self._flat = None
         self._anchor = None
         self._grad_hook = None       # DDP: called with tape marks during the last backward level
+        # opt-in: run the L identical level passes of a hierarchical model once (see _run)
+        self.dedup_passes = os.environ.get("HRSEG_DEDUP_PASSES", "0") == "1"
 
     # -- parameters -------------------------------------------------------------------------
     def flatten_parameters(self, device=None):
@@ -205,18 +221,25 @@ class _EngineModel(nn.Module):
             run.levels.append(lv)
             run.logits.append(z)
             return run
-        # The reference re-runs the backbone on the image for every level (D1).  In training that is
-        # faithful work (BN statistics update L times, gradients sum over the passes); in inference
-        # (eval mode, nothing recorded) the L passes are bit-identical, so the features are computed once.
-        shared = None
-        for L in range(len(self.levels)):
-            rec = Recorder(self.training, record, self._flat)
+        # The reference re-runs the backbone on the image for every level (D1): L bit-identical passes.
+        # Default in training: faithful re-execution (BN statistics update L times, gradients sum over
+        # the L tapes).  In inference (eval mode, nothing recorded) the features are computed once.
+        # `dedup_passes` (explicit opt-in, SURVEY.md "dedup mode") does the same in training: ONE pass
+        # whose BN layers apply their running-stat update L times, the L heads read the shared features,
+        # their feature gradients are summed and ONE reverse pass runs -- the same result up to fp32
+        # summation order at 1/L of the backbone work (executed FLOPs change; bench.py reports it apart).
+        n_levels = len(self.levels)
+        dedup = bool(self.dedup_passes) and self.training and n_levels > 1
+        run.shared_tape = dedup and record
+        shared, shared_rec = None, None
+        for L in range(n_levels):
             if shared is None:
+                rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1)
                 feats = self._backbone(rec, x_nhwc)
-                if not self.training and not record:
-                    shared = feats
+                if dedup or (not self.training and not record):
+                    shared, shared_rec = feats, rec
             else:
-                feats = shared
+                feats, rec = shared, shared_rec
             film = self.films[L - 1] if L > 0 else None
             z, lv = self._head_forward(rec, feats, self._level_head(L), film, run.probs[L - 1] if L > 0 else None, size)
             groups = None
@@ -264,8 +287,12 @@ class _EngineModel(nn.Module):
         else:
             dzl = ops.nchw_to_nhwc(dz)
         dgb = ops.zeros(lv["gb"].shape, torch.float32, lv["gb"].device) if film is not None else None
-        feats.grad = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
-                                  head.bias._hr_gstore, dgb, cout=head.out_channels)
+        g = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
+                         head.bias._hr_gstore, dgb, cout=head.out_channels)
+        if feats.grad is None:
+            feats.grad = g
+        else:                            # shared features (de-duplicated passes): sum over the levels' heads
+            ops.add(feats.grad, g, out=feats.grad)
         if film is None:
             return None
         lin = film.mlp[1]

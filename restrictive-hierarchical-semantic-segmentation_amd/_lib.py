@@ -38,7 +38,8 @@ class BnFwd(C.Structure):
     """hrseg_bn_fwd_t"""
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
-                ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i)]
+                ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
+                ("stat_updates", _i)]
 
 
 class BnBwd(C.Structure):
@@ -128,8 +129,16 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
+ABI_VERSION = 2     # must equal hrseg_abi_version() of the built library (struct layouts above)
+
+
 def abi_version() -> int:
     return int(_lib.hrseg_abi_version())
+
+
+if abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this package needs {ABI_VERSION}: rebuild it "
+                      "(`make -C restrictive-hierarchical-semantic-segmentation_amd/csrc`)")
 
 
 def last_error() -> str:

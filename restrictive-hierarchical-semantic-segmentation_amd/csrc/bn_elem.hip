@@ -634,7 +634,10 @@ __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
   const int C = p.C, c = local * 16 + (threadIdx.x & 15);
   double s, ss;
   reduce_chunks16(p.partial, p.nchunks, C, c, s, ss, red);
-  if (local == 0 && threadIdx.x == 0 && p.num_batches_tracked) *(long long*)p.num_batches_tracked += 1;
+  // stat_updates > 1: the same batch statistics enter the running averages that many times (the
+  // de-duplicated level passes of the hierarchical models) -- sequential updates, bit for bit
+  const int reps = p.stat_updates > 1 ? p.stat_updates : 1;
+  if (local == 0 && threadIdx.x == 0 && p.num_batches_tracked) *(long long*)p.num_batches_tracked += reps;
   if (threadIdx.x >= 16 || c >= C) return;
   const double mean = s / (double)p.npix;
   double var = ss / (double)p.npix - mean * mean;
@@ -645,10 +648,16 @@ __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
   p.coef[C + c] = rstd;
   p.coef[2 * C + c] = ga * rstd;
   p.coef[3 * C + c] = be - (float)mean * ga * rstd;
-  if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+  if (p.running_mean) {
+    float rm = p.running_mean[c];
+    for (int r = 0; r < reps; ++r) rm = (1.f - p.momentum) * rm + p.momentum * (float)mean;
+    p.running_mean[c] = rm;
+  }
   if (p.running_var) {
     const double unb = (p.npix > 1) ? var * (double)p.npix / (double)(p.npix - 1) : var;
-    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+    float rv = p.running_var[c];
+    for (int r = 0; r < reps; ++r) rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
+    p.running_var[c] = rv;
   }
 }
 

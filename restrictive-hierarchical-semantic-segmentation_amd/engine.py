@@ -141,9 +141,10 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None):
+    def __init__(self, training, record, flat=None, bn_repeat=1):
         self.training = training
         self.record = record
+        self.bn_repeat = bn_repeat   # running-stat updates per BN (de-duplicated level passes)
         self.tape = []
         self.flat = flat
         self.wt_cache = {}
@@ -207,7 +208,7 @@ class Recorder:
                                     [c.out_channels for _, c, _, _ in items])
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
-                         residual=res.data if res is not None else None, relu=relu,
+                         residual=res.data if res is not None else None, relu=relu, repeat=self.bn_repeat,
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
         zc = ops.bn_fwd_group(bn_items, self.training)

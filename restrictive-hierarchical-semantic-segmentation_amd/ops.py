@@ -215,6 +215,7 @@ def bn_fwd_group(items, training):
         a.running_mean, a.running_var = ptr(it["rm"]), ptr(it["rv"])
         a.num_batches_tracked = ptr(it["nbt"]) if training else None
         a.momentum, a.eps = float(it["momentum"]), float(it["eps"])
+        a.stat_updates = int(it.get("repeat", 1))
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         if training:

@@ -238,3 +238,64 @@ def test_train_epoch_and_test_loops_run():
            for L, (p, tt) in enumerate(zip(probs, targets))]
     vec = PT._metric_vectors(cms)
     assert abs(iou_l[0] - float(vec["iou"].mean())) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["unet_hier_ext_32", "hrnet_hier_tl_64"])
+def test_dedup_passes_equals_faithful_passes(name):
+    """opt-in `dedup_passes`: one backbone pass + L running-stat updates + summed head gradients must give
+    what the L faithfully re-executed passes give: logits, loss, BN buffers (incl. num_batches_tracked = L)
+    and every parameter gradient (fp32 summation order is the only difference)."""
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd import train as PT
+    from hrseg_amd.Metrics import losses as PL
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    num_classes = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    args = _args(kind, hier, num_classes, weights, batch)
+    results = []
+    for dedup in (False, True, False):
+        model = build_model(PM, kind, hier, tree, size).cuda()
+        model.dedup_passes = dedup
+        model.train()
+        probs, logits = PT._model_call(model, x, args, tree)
+        targets = PT.split_targets(target, args)
+        loss = 0.0
+        for L, (z, t) in enumerate(zip(logits, targets)):
+            ce, dice = PL.fused_ce_dice(z, t, weights[L])[:2]
+            loss = loss + ce + dice
+        loss = loss + PL.hierarchical_consistency_loss(probs, model.levels, model.parent_of)   # gradient into probs too
+        loss.backward()
+        results.append(dict(logits=[z.detach().cpu().numpy() for z in logits], loss=float(loss),
+                            grads={n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()},
+                            bufs={n: b.detach().cpu().numpy() for n, b in model.named_buffers()}))
+    ref, ded, ref2 = results          # ref2: a second faithful run = the run-to-run noise of the atomics
+    assert abs(ref["loss"] - ded["loss"]) < 1e-5 * max(1.0, abs(ref["loss"]))
+    for a, b in zip(ref["logits"], ded["logits"]):
+        assert rel_err(b, a) < 1e-5
+    n_levels = len(ref["logits"])
+    for n, b in ref["bufs"].items():
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == n_levels and int(ded["bufs"][n]) == n_levels, n
+        else:
+            # sequential updates with the same statistics; split-K atomics make conv outputs (hence the
+            # statistics) differ in the last bits from pass to pass
+            assert rel_err(ded["bufs"][n], b) < 1e-5, n
+    def worst_of(other):
+        w, wn = 0.0, None
+        for n, ga in ref["grads"].items():
+            e = float(np.abs(ga - other["grads"][n]).max()) / max(float(np.abs(ga).max()), 1e-6)
+            if e > w:
+                w, wn = e, n
+        return w, wn
+    worst, worst_name = worst_of(ded)
+    worst_noise, noise_name = worst_of(ref2)
+    print(f"dedup vs faithful: worst {worst:.3e} ({worst_name}); faithful vs faithful: {worst_noise:.3e} ({noise_name})")
+    # both are fp32 evaluations of the same sums in different order; early layers sit on the ~1e-2 fp32
+    # noise floor of this net (tools/grad_noise.py), so the bound is that floor, not rounding
+    assert worst < max(1e-1, 4 * worst_noise), (worst, worst_name, worst_noise)
+    med = np.median([rel_err(ded["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
+    noise = np.median([rel_err(ref2["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
+    assert med < max(3e-3, 4 * noise), (med, noise)
