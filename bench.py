@@ -256,7 +256,7 @@ def main():
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
         line = {
-            "metric": "train images/sec (620x620, hier-HRNet-W48)" if (args.model == "hrnet" and hier) else
+            "metric": "train images/sec (620x620, hier-HRNet-W48)" if (args.model == "hrnet" and hier and args.size == 620) else
             "train images/sec (%dx%d, %s%s)" % (args.size, args.size, "hier-" if hier else "flat-", args.model),
             "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),

@@ -299,3 +299,48 @@ def test_dedup_passes_equals_faithful_passes(name):
     med = np.median([rel_err(ded["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     noise = np.median([rel_err(ref2["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     assert med < max(3e-3, 4 * noise), (med, noise)
+
+
+def test_full_size_step_properties():
+    """BASELINE.json's headline configuration (hier HRNet-W48, 620x620, batch 4) is too large for the CPU
+    oracle inside a test; the step is checked through size-independent properties of the path:
+    composition (children of a group sum to the parent's probability, level 0 is a sigmoid), masked
+    predictions, confusion-matrix bookkeeping, finite loss/gradients, BN bookkeeping of the L passes."""
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT, ops
+    from hrseg_amd.utils import synth
+    tree = load_tree("class_tree_tl.json")
+    model = build_model(PM, "hrnet", True, tree, 620).cuda()
+    x_np, t_np = synth.synthetic_batch(tree, 4, 620, seed=9, hierarchical=True)
+    x, target = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
+    weights = level_weights_for("class_tree_tl.json", True)
+    args = _args("hrnet", True, [4, 4], weights, 4)
+    model.train()
+    probs, logits = PT._model_call(model, x, args, tree)
+    assert [tuple(p.shape) for p in probs] == [(4, 4, 620, 620)] * 2
+    p0, p1 = probs[0].detach(), probs[1].detach()
+    assert float((p0 - torch.sigmoid(logits[0].detach())).abs().max()) < 1e-6
+    # tl tree: the four level-1 classes are the children of 'tooth' (level-0 channel 3)
+    assert float((p1.sum(1) - p0[:, 3]).abs().max()) < 1e-5
+    assert float(p1.min()) >= 0.0 and float(p0.max()) <= 1.0
+    targets = PT.split_targets(target, args)
+    loss = 0.0
+    for L, (z, t) in enumerate(zip(logits, targets)):
+        onehot, cm = ops.predict_metrics(z.detach(), t, child=(L > 0), mask_pred=True)
+        valid = (t != -1).all(1)
+        assert float(onehot.sum(1)[valid].min()) == 1.0 and float(onehot.sum(1)[~valid].max() if (~valid).any() else 0) == 0.0
+        # every valid pixel is counted once (child levels: pixels outside the parent carry the synthetic class 0)
+        assert int(cm.sum()) == 4 * 620 * 620
+        ce, dice = PL.fused_ce_dice(z, t, weights[L])[:2]
+        assert torch.isfinite(ce) and torch.isfinite(dice)
+        loss = loss + ce + dice
+    loss.backward()
+    total = 0.0
+    for n, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        total += float(p.grad.double().pow(2).sum())
+    assert total > 0.0
+    for n, b in model.named_buffers():
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == 2, n                  # two level passes -> two running-stat updates (D1)
