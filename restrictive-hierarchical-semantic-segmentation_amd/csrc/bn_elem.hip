@@ -89,11 +89,28 @@ __device__ __forceinline__ void reduce_chunks16(const double* __restrict__ parti
                                                double& s0, double& s1, double* red) {
   const int lane = threadIdx.x >> 4;  // 0..15
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int k = lane; k < nchunks; k += 16) {
+  if (c < C) {
+    // up to 16 chunks per lane: issue the loads in batches of 4 chunks (8 independent loads in flight)
+    // instead of a load-add chain of cold-memory latencies
+    int k = lane;
+    for (; k + 48 < nchunks; k += 64) {
+      double t0[4], t1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t0[u] = partial[((size_t)(k + 16 * u) * 2 + 0) * C + c];
+        t1[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a += t0[u];
+        b += t1[u];
+      }
+    }
+    for (; k < nchunks; k += 16) {
       a += partial[((size_t)k * 2 + 0) * C + c];
       b += partial[((size_t)k * 2 + 1) * C + c];
     }
+  }
   red[threadIdx.x * 2] = a;
   red[threadIdx.x * 2 + 1] = b;
   __syncthreads();
@@ -375,48 +392,69 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
   }
 }
 
-// gather form of the transpose: every input pixel sums the output pixels that read it
+// gather form of the transpose: every input pixel sums the output pixels that read it (no atomics,
+// deterministic).  An 8x resize gives each input pixel an ~18x18 footprint and only a few thousand input
+// pixels: RS sub-lanes per pixel split the footprint rows (thread = channel quad x pixel lane x row split)
+// and reduce through LDS, so the small tensors still fill the machine.
+template <int RS>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dout, int lddout, int B,
                                                            int Hi, int Wi, int C, float* __restrict__ din,
                                                            int lddin, int Hout, int Wout, int Hr, int Wr, int py,
                                                            int px, float sh, float sw, int align, int acc) {
-  const Lanes L = make_lanes(C);
-  if (!L.active) return;
+  __shared__ f32x4 red[256];
+  const int Q = C >> 2;
+  const int P2 = max(1, 256 / (Q * RS));           // pixel lanes per block
+  const int cq = threadIdx.x % Q, pl = (threadIdx.x / Q) % P2, rs = threadIdx.x / (Q * P2);
+  const bool active = rs < RS && (int)threadIdx.x < Q * P2 * RS;
   const long npix = (long)B * Hi * Wi;
   const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
-  FOR_PIXELS(pix, L, npix) {
-    const int b = (int)(pix / ((long)Hi * Wi));
-    const int rem = (int)(pix - (long)b * Hi * Wi);
-    const int iy = rem / Wi, ix = rem - iy * Wi;
-    // candidate output rows/cols: src in (iy-1, iy+1)  (whole range when scale is 0)
-    int oy_lo = 0, oy_hi = Hr - 1, ox_lo = 0, ox_hi = Wr - 1;
-    if (sh > 0.f) {
-      oy_lo = max(0, (int)floorf(((float)iy - 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) - 1);
-      oy_hi = min(Hr - 1, (int)ceilf(((float)iy + 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) + 1);
-    }
-    if (sw > 0.f) {
-      ox_lo = max(0, (int)floorf(((float)ix - 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) - 1);
-      ox_hi = min(Wr - 1, (int)ceilf(((float)ix + 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) + 1);
-    }
+  for (long base = (long)blockIdx.x * P2; base < npix; base += (long)gridDim.x * P2) {
+    const long pix = base + pl;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      int y0, y1;
-      float ly0, ly1;
-      src_index(oy, sh, Hi, align, y0, y1, ly0, ly1);
-      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
-      if (wy == 0.f) continue;
-      const float* row = dout + (((size_t)b * Hout + oy + py) * Wout + px) * lddout + 4 * L.cq;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        int x0, x1;
-        float lx0, lx1;
-        src_index(ox, sw, Wi, align, x0, x1, lx0, lx1);
-        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
-        if (wx == 0.f) continue;
-        s += (wy * wx) * ld4(row + (size_t)ox * lddout);
+    if (active && pix < npix) {
+      const int b = (int)(pix / ((long)Hi * Wi));
+      const int rem = (int)(pix - (long)b * Hi * Wi);
+      const int iy = rem / Wi, ix = rem - iy * Wi;
+      // candidate output rows/cols: src in (iy-1, iy+1)  (whole range when scale is 0)
+      int oy_lo = 0, oy_hi = Hr - 1, ox_lo = 0, ox_hi = Wr - 1;
+      if (sh > 0.f) {
+        oy_lo = max(0, (int)floorf(((float)iy - 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) - 1);
+        oy_hi = min(Hr - 1, (int)ceilf(((float)iy + 1.f + (align ? 0.f : 0.5f)) * ish - (align ? 0.f : 0.5f)) + 1);
+      }
+      if (sw > 0.f) {
+        ox_lo = max(0, (int)floorf(((float)ix - 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) - 1);
+        ox_hi = min(Wr - 1, (int)ceilf(((float)ix + 1.f + (align ? 0.f : 0.5f)) * isw - (align ? 0.f : 0.5f)) + 1);
+      }
+      for (int oy = oy_lo + rs; oy <= oy_hi; oy += RS) {
+        int y0, y1;
+        float ly0, ly1;
+        src_index(oy, sh, Hi, align, y0, y1, ly0, ly1);
+        const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        const float* row = dout + (((size_t)b * Hout + oy + py) * Wout + px) * lddout + 4 * cq;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          int x0, x1;
+          float lx0, lx1;
+          src_index(ox, sw, Wi, align, x0, x1, lx0, lx1);
+          const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+          if (wx == 0.f) continue;
+          s += (wy * wx) * ld4(row + (size_t)ox * lddout);
+        }
       }
     }
-    float* d = din + pix * lddin + 4 * L.cq;
-    st4(d, acc ? ld4(d) + s : s);
+    if (RS > 1) {
+      __syncthreads();
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (active && rs == 0) {
+#pragma unroll
+        for (int r = 1; r < RS; ++r) s += red[threadIdx.x + r * Q * P2];
+      }
+    }
+    if (active && rs == 0 && pix < npix) {
+      float* d = din + pix * lddin + 4 * cq;
+      st4(d, acc ? ld4(d) + s : s);
+    }
   }
 }
 
@@ -869,9 +907,20 @@ extern "C" int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, 
                       py + Hr <= Hout && px + Wr <= Wout,
                   "hrseg_bilinear_bwd: bad geometry");
   const long npix = (long)B * Hi * Wi;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, dout, lddout, B,
-                     Hi, Wi, C, din, lddin, Hout, Wout, Hr, Wr, py, px, resize_scale(Hi, Hr, align_corners),
-                     resize_scale(Wi, Wr, align_corners), align_corners, accumulate);
+  // row splits: enough blocks to fill the chip, at most half the footprint rows, Q*RS <= 256
+  const int Q = C / 4;
+  const int foot = (Hi > 1 && Hr > 1) ? (int)(2.0 * (Hr - 1) / (Hi - 1)) + 3 : Hr;
+  int rs = 1;
+  while (rs < 8 && Q * rs * 2 <= 256 && rs * 2 <= foot / 2 && npix / max(1, 256 / (Q * rs)) < 1024) rs *= 2;
+  const int P2 = max(1, 256 / (Q * rs));
+  long blocks = (npix + P2 - 1) / P2;
+  if (blocks > 4096) blocks = 4096;
+  const float sh = resize_scale(Hi, Hr, align_corners), sw = resize_scale(Wi, Wr, align_corners);
+#define HRSEG_BIL(RS_) hipLaunchKernelGGL(bilinear_bwd_kernel<RS_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                                          dout, lddout, B, Hi, Wi, C, din, lddin, Hout, Wout, Hr, Wr, py, px, sh, sw,         \
+                                          align_corners, accumulate)
+  if (rs == 1) HRSEG_BIL(1); else if (rs == 2) HRSEG_BIL(2); else if (rs == 4) HRSEG_BIL(4); else HRSEG_BIL(8);
+#undef HRSEG_BIL
   HRSEG_LAUNCH_CHECK("bilinear_bwd");
   return 0;
 }

@@ -195,7 +195,8 @@ def test_maxpool(ops, H, W):
 
 
 @pytest.mark.parametrize("Hi,Wi,Ho,Wo,C", [(10, 10, 20, 20, 64), (20, 20, 155, 155, 48), (39, 39, 155, 155, 16),
-                                           (7, 9, 14, 18, 128), (1, 1, 4, 4, 16), (8, 8, 8, 8, 32)])
+                                           (7, 9, 14, 18, 128), (1, 1, 4, 4, 16), (8, 8, 8, 8, 32),
+                                           (20, 20, 155, 155, 384), (5, 7, 78, 78, 96), (3, 3, 40, 40, 1024)])
 def test_bilinear_align_corners(ops, Hi, Wi, Ho, Wo, C):
     g = torch.Generator().manual_seed(Hi + Ho)
     x = torch.randn(2, C, Hi, Wi, generator=g)
