@@ -150,7 +150,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """raw hipStream_t of torch's current stream on the current device (called once per launch: the
+    C-level accessor costs ~0.3 us, building a torch.cuda.Stream object ~4 us)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

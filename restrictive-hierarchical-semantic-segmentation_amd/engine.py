@@ -28,8 +28,14 @@ from . import ops
 _SIDE = {}
 
 
+_SIDE_ENABLED = None
+
+
 def wgrad_stream(device):
-    if os.environ.get("HRSEG_WGRAD_STREAM", "1") == "0":
+    global _SIDE_ENABLED
+    if _SIDE_ENABLED is None:            # read once: this runs per conv group
+        _SIDE_ENABLED = os.environ.get("HRSEG_WGRAD_STREAM", "1") != "0"
+    if not _SIDE_ENABLED:
         return None
     s = _SIDE.get(device)
     if s is None:
