@@ -127,6 +127,16 @@ class FlatParams:
         lo, hi = p._hr_tstore_range
         return self.data_t[lo:hi]
 
+    def view_of(self, flat_tensor, p):
+        """the slice of another flat buffer (optimizer moments ...) that belongs to parameter p, in p's
+        logical shape (conv weights: [Cout,Cin,kh,kw] view of the OHWI storage)"""
+        lo, hi = p._hr_range
+        store = flat_tensor[lo:hi]
+        if p.dim() == 4:
+            o, i, kh, kw = p.shape
+            return store.view(o, kh, kw, i).permute(0, 3, 1, 2)
+        return store.view(p.shape)
+
     def valid(self, device):
         """False once .to()/.cuda() rebound the parameters to fresh storages."""
         return (self.device == device and self._first.data_ptr() == self.data.data_ptr()

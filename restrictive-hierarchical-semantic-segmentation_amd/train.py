@@ -75,16 +75,74 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in self.param_groups[0]["params"]:
                 p.grad = None
 
+    def _moments(self):
+        flat = self.model.flatten_parameters()
+        if self._m is None or self._m.numel() != flat.numel or self._m.device != flat.data.device:
+            self._m = torch.zeros_like(flat.data)
+            self._v = torch.zeros_like(flat.data)
+        return flat
+
     def state_dict(self):
+        """torch.optim.AdamW's format (what the reference writes into best.pt / last.pt, train.py:668-703):
+        {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [0..n-1]}]}, the
+        per-parameter moments being [Cout,Cin,kh,kw]-shaped copies out of the flat buffers."""
         if self._state is not None:
             self._step = int(self._state[0].item())      # graph replays advance the device counter
-        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups":
-                [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        params = self.param_groups[0]["params"]
+        group["params"] = list(range(len(params)))
+        state = {}
+        if self._m is not None and self._step > 0:
+            flat = self._moments()
+            for i, p in enumerate(params):
+                state[i] = {"step": torch.tensor(float(self._step)),
+                            "exp_avg": flat.view_of(self._m, p).contiguous().clone(),
+                            "exp_avg_sq": flat.view_of(self._v, p).contiguous().clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self._step, self._m, self._v = sd["step"], sd["exp_avg"], sd["exp_avg_sq"]
-        self.param_groups[0].update(sd["param_groups"][0])
+        """accepts torch.optim.AdamW's state_dict (a checkpoint of the reference) or the one above"""
+        group = dict(sd["param_groups"][0])
+        group.pop("params", None)
+        self.param_groups[0].update(group)
+        params = self.param_groups[0]["params"]
+        state = sd.get("state", {})
+        flat = self._moments()
+        ops.fill(self._m, 0.0)
+        ops.fill(self._v, 0.0)
+        step = 0
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                st = state.get(i, state.get(str(i)))
+                if st is None:
+                    continue
+                flat.view_of(self._m, p).copy_(st["exp_avg"].to(self._m.device))
+                flat.view_of(self._v, p).copy_(st["exp_avg_sq"].to(self._v.device))
+                step = max(step, int(float(st["step"])))
+        self._step = step
         self._hyper = None                                # rebuilt (with the loaded step) on the next step
+
+
+def save_checkpoint(path, model, optimizer, epoch, loss, test_measure_mean=None, test_measure_std=None):
+    """the checkpoint dict of the reference (train.py:668-680, 689-703), written atomically like there
+    (new_*.pt then rename); loadable by the reference's own torch.load + load_state_dict"""
+    import os
+    tmp = os.path.join(os.path.dirname(path) or ".", "new_" + os.path.basename(path))
+    sd = {k: v.detach().contiguous().cpu() for k, v in _unwrap(model).state_dict().items()}
+    torch.save({"epoch": epoch, "model_state_dict": sd, "optimizer_state_dict": optimizer.state_dict(),
+                "loss": loss, "test_measure_mean": test_measure_mean, "test_measure_std": test_measure_std}, tmp)
+    if os.path.exists(path):
+        os.remove(path)
+    os.rename(tmp, path)
+
+
+def load_checkpoint(path, model, optimizer=None, device="cuda"):
+    """resume from a best.pt / last.pt written by the reference or by save_checkpoint -> the checkpoint dict"""
+    ck = torch.load(path, map_location="cpu")
+    _unwrap(model).load_state_dict(ck["model_state_dict"])
+    if optimizer is not None and "optimizer_state_dict" in ck:
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+    return ck
 
 
 # ----------------------------------------------------------------------------- metrics

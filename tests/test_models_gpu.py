@@ -344,3 +344,73 @@ def test_full_size_step_properties():
     for n, b in model.named_buffers():
         if n.endswith("num_batches_tracked"):
             assert int(b) == 2, n                  # two level passes -> two running-stat updates (D1)
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """save_checkpoint writes the reference's checkpoint dict (model_state_dict + torch.optim.AdamW-format
+    optimizer_state_dict, train.py:668-703): a stock torch AdamW on the CPU oracle model loads it, and a
+    fresh product model/optimizer resumed from the file continues exactly like the one that never stopped."""
+    from oracle import models as OM
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    name = "unet_hier_tl_62"
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    num_classes = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    args = _args(kind, hier, num_classes, weights, batch)
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    loss_fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in num_classes]
+
+    pm = build_model(PM, kind, hier, tree, size).cuda()
+    popt = PT.FusedAdamW(pm, lr=[1e-3])
+    pm.train()
+    ll = []
+    for _ in range(2):
+        loss, _ = PT.train_step(pm, popt, x, target, loss_fns, args, tree, ll)
+    path = str(tmp_path / "last.pt")
+    PT.save_checkpoint(path, pm, popt, epoch=3, loss=float(loss), test_measure_mean=0.5, test_measure_std=0.1)
+
+    # (1) the file is what the reference's loader expects
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "test_measure_mean", "test_measure_std"}
+    om = build_model(OM, kind, hier, tree, size)
+    om.load_state_dict(ck["model_state_dict"])
+    oopt = torch.optim.AdamW(om.parameters(), lr=1e-3)
+    oopt.load_state_dict(ck["optimizer_state_dict"])
+    st = oopt.state_dict()["state"]
+    params = list(om.parameters())
+    assert len(st) == len(params) and all(float(st[i]["step"]) == 2.0 for i in st)
+    for i, p in enumerate(params):
+        assert st[i]["exp_avg"].shape == p.shape and st[i]["exp_avg_sq"].shape == p.shape
+    flat = pm.flatten_parameters()
+    some = [i for i, p in enumerate(pm.parameters()) if p.dim() == 4][:3]
+    for i in some:
+        p = list(pm.parameters())[i]
+        assert torch.equal(st[i]["exp_avg"], flat.view_of(popt._m, p).cpu())
+
+    # (2) resume: a fresh model + optimizer from the file takes the same third step
+    pm2 = build_model(PM, kind, hier, tree, size).cuda()
+    popt2 = PT.FusedAdamW(pm2, lr=[5e-2])                  # overwritten by the checkpoint's param_groups
+    ck2 = PT.load_checkpoint(path, pm2, popt2)
+    assert ck2["epoch"] == 3 and popt2.param_groups[0]["lr"] == 1e-3
+    pm2.train()
+    l1, _ = PT.train_step(pm, popt, x, target, loss_fns, args, tree, ll)
+    l2, _ = PT.train_step(pm2, popt2, x, target, loss_fns, args, tree, [])
+    assert abs(float(l1) - float(l2)) < 1e-5 * abs(float(l1))
+    sd1, sd2 = pm.state_dict(), pm2.state_dict()
+    for n in sd1:
+        a, b = sd1[n].double(), sd2[n].double()
+        # identical inputs and state; split-K / weight-gradient atomics reorder sums run to run, and Adam
+        # turns a sign flip of a noise-level gradient into +-lr
+        assert float((a - b).abs().max()) <= 2.1e-3 + 1e-4 * float(b.abs().max()), n
+
+    # (3) a state_dict written by stock torch AdamW (= a checkpoint of the reference) loads as well
+    popt3 = PT.FusedAdamW(pm2, lr=[1e-3])
+    popt3.load_state_dict(oopt.state_dict())
+    assert popt3._step == 2
+    for i in some:
+        p = list(pm2.parameters())[i]
+        assert torch.equal(pm2.flatten_parameters().view_of(popt3._m, p).cpu(), st[i]["exp_avg"])
