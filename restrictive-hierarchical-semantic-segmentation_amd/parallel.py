@@ -106,6 +106,21 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
 
+def all_reduce_confusion(cms, group=None):
+    """Global per-step metrics under data parallelism: sum the per-level confusion counts (int64,
+    (C+child)^2 entries each) over the ranks.  The reference computes its metrics on the batch gathered
+    on GPU 0 (nn.DataParallel); summed counts give exactly those values.  One small collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not cms:
+        return cms
+    flat = torch.cat([c.reshape(-1) for c in cms])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, o = [], 0
+    for c in cms:
+        out.append(flat[o:o + c.numel()].view_as(c))
+        o += c.numel()
+    return out
+
+
 def init_distributed():
     """Process group from torchrun's environment; returns (rank, local_rank, world)."""
     import os

@@ -323,6 +323,9 @@ def train_epoch(model, device, train_loader, optimizer, epoch, lossFuncts, args,
     for batch_idx, (data, target) in enumerate(train_loader):
         data, target = data.to(device), target.to(device)
         loss, cms = train_step(model, optimizer, data, target, lossFuncts, args, class_tree, levelLoss, epoch_num)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            from .parallel import all_reduce_confusion
+            cms = all_reduce_confusion(cms)          # metrics of the global batch, as on the reference's GPU 0
         vec = _metric_vectors(cms)
         # the only device->host copy of the step: loss + every per-class metric
         host = torch.cat([loss.reshape(1)] + [vec[k] for k in METRIC_NAMES]).tolist()

@@ -41,6 +41,17 @@ def _worker(rank, world, port):
         for (lo, hi), (lo2, hi2) in zip(spans, spans[1:]):
             assert hi2 == lo and lo2 < hi2
         assert len(spans) >= 4
+    # global metrics: per-level confusion counts summed over the ranks = counts of the gathered batch
+    from hrseg_amd.parallel import all_reduce_confusion
+    from hrseg_amd.Metrics.performance_metrics import metrics_from_confusion
+    g = torch.Generator().manual_seed(5)
+    parts = [[torch.randint(0, 50, (4, 4), generator=g), torch.randint(0, 50, (5, 5), generator=g)] for _ in range(world)]
+    got = all_reduce_confusion([c.clone() for c in parts[rank]])
+    for L, c in enumerate(got):
+        want = sum(parts[r][L] for r in range(world))
+        assert c.dtype == torch.int64 and torch.equal(c, want)
+        m = metrics_from_confusion(c, child_classes=(L > 0))
+        assert torch.allclose(m["iou"], metrics_from_confusion(want, child_classes=(L > 0))["iou"])
     dist.destroy_process_group()
 
 
