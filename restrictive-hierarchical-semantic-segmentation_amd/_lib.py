@@ -112,6 +112,18 @@ _lib.hrseg_debug_set_wgrad_tune.restype = _i
 _lib.hrseg_debug_set_wgrad_tune.argtypes = [_i, _i, _i]
 
 
+_lib.hrseg_debug_set_wgrad_row.restype = _i
+_lib.hrseg_debug_set_wgrad_row.argtypes = [_i]
+
+
+def set_wgrad_row(on=1):
+    _lib.hrseg_debug_set_wgrad_row(int(on))
+
+
+if "HRSEG_WGRAD_ROW" in os.environ:          # A/B switch for tuning runs
+    set_wgrad_row(int(os.environ["HRSEG_WGRAD_ROW"]))
+
+
 def set_wgrad_tune(pix=0, db=0, target_blocks=0):
     _lib.hrseg_debug_set_wgrad_tune(pix, db, target_blocks)
 

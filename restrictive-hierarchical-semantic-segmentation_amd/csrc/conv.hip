@@ -761,6 +761,7 @@ struct WgradArgs {
   int ks, stride, T;
   int pix_per_block;  // multiple of the stage size
   float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
+  int row;            // 1: wgrad_row_body (3x3 stride 1): a block owns one kernel ROW (3 taps)
 };
 
 // Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
@@ -896,6 +897,177 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
     }
 }
 
+// 3x3 stride-1 variant: a block owns one kernel ROW kh (taps kw = -1, 0, +1), a cout tile, a cin tile
+// and a pixel range.  Each stage loads the dy tile [64 px] and the x tile of the neighbour pixels
+// [66 px, shifted by kh image rows] ONCE and runs the three taps on them: the x operand of tap kw
+// for output pixel m is LDS row (m - first + kw + 1).  Same global loads per stage as the one-tap body,
+// three times the MFMAs: vector-memory instructions per MFMA drop 3x (they are what holds the
+// matrix pipe back).  Pixels at the left/right image border must not see the wrapped
+// neighbour: per-pixel masks (staged next to the tiles) zero the dy operand for kw = -1 / +1 there;
+// rows above/below the image are zero-filled at load time.
+template <int TN, int TK>
+__device__ __forceinline__ void wgrad_row_body(const WgradArgs& p, float* lds, const int bx, int id) {
+  constexpr int PIX = 64, BROWS = PIX + 2;
+  constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);
+  constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
+  float* la = lds;
+  float* lb = lds + PIX * SA;
+  float* lm = lb + BROWS * SB;                       // [2][PIX]: left-border / right-border masks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
+  const int kt = id % nkt;
+  id /= nkt;
+  const int ct = id % nct;
+  const int khi = id / nct;                          // 0..2
+  const int n0 = ct * 16 * TN, k0 = kt * 16 * TK;
+  const int kh = khi - 1;
+  const int H = p.Ho, W = p.Wo, hw = H * W;
+
+  const int lo = bx * p.pix_per_block;
+  const int hi = min(lo + p.pix_per_block, p.M);
+  const int nstages = (hi - lo + PIX - 1) / PIX;
+  const int q = tid & 3, r0 = tid >> 2;
+
+  const int b_lo = max(lo - 1, 0) / hw;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc(p.x + (size_t)b_lo * hw * p.ldx, (size_t)(p.B - b_lo) * hw * p.ldx * 4);
+
+  // byte offset of neighbour-space pixel pb (its image row shifted by kh), or OOB
+  auto x_off = [&](int pb) -> unsigned {
+    if (pb < 0 || pb >= p.M) return HRSEG_BUF_OOB;
+    const int b = fdiv(pb, hw, p.rcp_hw);
+    const int rem = pb - b * hw;
+    const int y = fdiv(rem, W, p.rcp_w), x = rem - y * W;
+    const int iy = y + kh;
+    if (iy < 0 || iy >= H) return HRSEG_BUF_OOB;
+    return ((unsigned)(((b - b_lo) * H + iy) * W + x) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u;
+  };
+
+  f32x4 ra[TN], rb[TK], rbx[TK];
+  float mL = 0.f, mR = 0.f;
+  auto stage_load = [&](int s) {
+    const int ml = s * PIX + r0;                     // row inside the block's range
+    const int m = lo + ml;
+    const bool ok = m < hi;
+    const unsigned dyo = ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ra[j] = buf_load4(rdy, dyo, 64 * j);
+    const int b = fdiv(m, hw, p.rcp_hw);
+    const int rem = m - b * hw;
+    const int oy = fdiv(rem, W, p.rcp_w), ox = rem - oy * W;
+    mL = (ox != 0) ? 1.f : 0.f;
+    mR = (ox != W - 1) ? 1.f : 0.f;
+    const unsigned xo = x_off(m - 1);
+#pragma unroll
+    for (int j = 0; j < TK; ++j) rb[j] = buf_load4(rx, xo, 64 * j);
+    if (tid < 8) {                                   // the two extra neighbour rows of the stage
+      const unsigned xe = x_off(lo + s * PIX + PIX + (tid >> 2) - 1);
+#pragma unroll
+      for (int j = 0; j < TK; ++j) rbx[j] = buf_load4(rx, xe, 64 * j);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(la + r0 * SA + 16 * j + 4 * q) = ra[j];
+#pragma unroll
+    for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(lb + r0 * SB + 16 * j + 4 * q) = rb[j];
+    if (tid < 8) {
+#pragma unroll
+      for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(lb + (PIX + (tid >> 2)) * SB + 16 * j + 4 * q) = rbx[j];
+    }
+    if (q == 0) {
+      lm[r0] = mL;
+      lm[PIX + r0] = mR;
+    }
+  };
+
+  f32x4 acc[3][TN][TK];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int k = 0; k < TK; ++k) acc[t][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nstages > 0) {
+    stage_load(0);
+    stage_store();
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) stage_load(s + 1);
+#pragma unroll
+    for (int ks4 = 0; ks4 < PIX / 16; ++ks4) {
+      const int row = wave * (PIX / 4) + ks4 * 4 + (lane >> 4);
+      float af[TN], afl[TN], afr[TN];
+      const float wl = lm[row], wr = lm[PIX + row];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        af[n] = la[row * SA + 16 * n + (lane & 15)];
+        afl[n] = af[n] * wl;
+        afr[n] = af[n] * wr;
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float bf[TK];
+#pragma unroll
+        for (int k = 0; k < TK; ++k) bf[k] = lb[(row + t) * SB + 16 * k + (lane & 15)];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int k = 0; k < TK; ++k)
+            acc[t][n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? afl[n] : t == 2 ? afr[n] : af[n], bf[k],
+                                                                acc[t][n][k], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) stage_store();
+    __syncthreads();
+  }
+
+  // cross-wave reduction, one tap at a time: red[wave][tile][r*64 + lane]
+  const int r = tid >> 6, l = tid & 63;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int k = 0; k < TK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[((wave * TN + n) * TK + k) * 256 + e * 64 + lane] = acc[t][n][k][e];
+    __syncthreads();
+    const int tap = khi * 3 + t;
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int k = 0; k < TK; ++k) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += lds[((wv * TN + n) * TK + k) * 256 + tid];
+        const int co = n0 + 16 * n + 4 * (l >> 4) + r;
+        const int ci = k0 + 16 * k + (l & 15);
+        atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
+      }
+    __syncthreads();
+  }
+}
+
+template <int TN, int TK>
+struct WgradRowLds {
+  static constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16), SB = 16 * TK + ((TK % 2) ? 0 : 16);
+  static constexpr int STAGE = 64 * SA + 66 * SB + 128, RED = 4 * TN * TK * 256;
+  static constexpr int FLOATS = (STAGE > RED) ? STAGE : RED;
+};
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_row_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradRowLds<TN, TK>::FLOATS];
+  const int tiles = gridDim.y, nblk = gridDim.x * gridDim.y;
+  const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
+  wgrad_row_body<TN, TK>(p, lds, r / tiles, r % tiles);
+}
+
 template <int TN, int TK, int PIX, int DB>
 struct WgradLds {
   static constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16), SB = 16 * TK + ((TK % 2) ? 0 : 16);
@@ -930,7 +1102,28 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup grp) {
   wgrad_body<TN, TK, PIX, DB>(grp.a[g], lds, r / tiles, r % tiles);
 }
 
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_row_group_kernel(WgradGroup grp) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradRowLds<TN, TK>::FLOATS];
+  int g = 0;
+  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
+  const int lo = g ? grp.blk_end[g - 1] : 0;
+  const int nblk = grp.blk_end[g] - lo;
+  const int tiles = nblk / grp.gx[g];
+  const int r = xcd_remap(blockIdx.x - lo, nblk);
+  wgrad_row_body<TN, TK>(grp.a[g], lds, r / tiles, r % tiles);
+}
+
 static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
+// opt-in (hrseg_debug_set_wgrad_row / HRSEG_WGRAD_ROW=1): 3x3 stride-1 convs with 48-channel tiles use
+// wgrad_row_body.  Measured equal to the one-tap body (group of the four branch convs 192 vs 183 us alone,
+// 90.4 vs 90.7 ms per train step): 3x fewer vector-memory instructions per MFMA buy nothing here, the
+// short kernels are bound by ramp-up, the cross-wave reduction and the atomics, not by the stage loop.
+static int g_wgrad_row = 0;
+extern "C" int hrseg_debug_set_wgrad_row(int on) { g_wgrad_row = on; return 0; }
+static bool wgrad_row_ok(const WgradArgs& a, int tn, int tk) {
+  return g_wgrad_row && a.ks == 3 && a.stride == 1 && tn == 3 && tk == 3;
+}
 extern "C" int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks) {
   g_tune_wg_pix = pix; g_tune_wg_db = db; g_tune_wg_blocks = target_blocks;
   return 0;
@@ -961,9 +1154,32 @@ static int launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
 }
 
 template <int TN, int TK>
+static int launch_wgrad_row(WgradArgs a, hipStream_t st) {
+  // three taps per block: a third of the tile sets, so the pixel ranges are cut finer for the same grid
+  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * 3;
+  int target = 7 * tiles;
+  if (target < 512) target = 512;
+  if (target > 4096) target = 4096;
+  if (g_tune_wg_blocks) target = g_tune_wg_blocks;
+  int ksplit = target / tiles;
+  if (ksplit < 1) ksplit = 1;
+  int ppb = ceil_div(ceil_div(a.M, ksplit), 64) * 64;
+  if (ppb < 2 * 64) ppb = 2 * 64;
+  a.pix_per_block = ppb;
+  a.row = 1;
+  if (int e = check_wgrad_span(a)) return e;
+  const int gx = ceil_div(a.M, ppb);
+  hipLaunchKernelGGL((wgrad_row_kernel<TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int TN, int TK>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   // measured (tools/wgrad_sweep.py): 64-pixel stages, single LDS buffer; grid of ~7 blocks per
   // output tile set, between 2 and 16 blocks per CU
+  if constexpr (TN == 3 && TK == 3) {
+    if (wgrad_row_ok(a, TN, TK)) return launch_wgrad_row<TN, TK>(a, st);
+  }
   const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
   int pix = 64, db = 1, target = 7 * tiles;
   if (target < 512) target = 512;
@@ -978,14 +1194,14 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 }
 
 static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
-  tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
+  tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * (a.row ? 3 : a.T);
   int target = 7 * tiles;
   if (target < 512) target = 512;
   if (target > 4096) target = 4096;
   int ksplit = target / tiles;
   if (ksplit < 1) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), pix) * pix;
-  if (ppb < 4 * pix) ppb = 4 * pix;
+  if (ppb < (a.row ? 2 : 4) * pix) ppb = (a.row ? 2 : 4) * pix;
   a.pix_per_block = ppb;
   gx = ceil_div(a.M, ppb);
 }
@@ -999,15 +1215,22 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
   WgradGroup g;
   g.n = n;
   int end = 0;
+  bool row = true;
+  for (int i = 0; i < n; ++i) row = row && wgrad_row_ok(a[i], tn, tk);
   for (int i = 0; i < n; ++i) {
     if (a[i].Cout % (16 * tn) || a[i].Cin % (16 * tk)) return 1;
     int gx, tiles;
+    a[i].row = row ? 1 : 0;
     plan_wgrad_blocks(a[i], tn, tk, 64, gx, tiles);
     if (check_wgrad_span(a[i])) return 1;   // the per-problem launch reports the error
     g.gx[i] = gx;
     end += gx * tiles;
     g.blk_end[i] = end;
     g.a[i] = a[i];
+  }
+  if (row) {
+    hipLaunchKernelGGL((wgrad_row_group_kernel<3, 3>), dim3(end), dim3(256), 0, st, g);
+    return 0;
   }
 #define WGG(TN_, TK_) if (tn == TN_ && tk == TK_) hipLaunchKernelGGL((wgrad_group_kernel<TN_, TK_, 64, 1>), dim3(end), dim3(256), 0, st, g);
   WGG(3, 3) WGG(3, 4) WGG(4, 3) WGG(4, 4)

@@ -38,7 +38,8 @@ CONV_CASES = [
     (48, 96, 3, 2, 31, 31, 2), (96, 192, 3, 2, 20, 18, 2), (64, 64, 3, 2, 33, 30, 2), (64, 256, 1, 1, 17, 17, 2),
     (144, 144, 1, 1, 15, 15, 2), (96, 48, 1, 1, 9, 9, 2), (384, 384, 3, 1, 10, 10, 2), (128, 64, 3, 1, 24, 24, 1),
     (192, 192, 3, 1, 39, 39, 4), (16, 32, 3, 1, 8, 8, 1), (3, 64, 3, 2, 30, 30, 2), (3, 64, 3, 1, 21, 17, 2),
-    (48, 48, 3, 1, 155, 155, 4),
+    (48, 48, 3, 1, 155, 155, 4), (48, 96, 3, 1, 7, 5, 3), (96, 48, 3, 1, 1, 9, 2), (48, 48, 3, 1, 64, 1, 2),
+    (144, 48, 3, 1, 13, 64, 1),
 ]
 
 
@@ -72,6 +73,28 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
         assert rel(nchw(dx), xr.grad) < 2e-5
         ops.conv_dgrad(dyd, wt, xd.shape, k, s, out=dx, accumulate=True)
         assert rel(nchw(dx), 2 * xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(48, 48, 3, 1, 37, 41, 2), (96, 96, 3, 1, 19, 23, 3), (48, 96, 3, 1, 7, 5, 3),
+                                  (96, 48, 3, 1, 1, 9, 2), (48, 48, 3, 1, 64, 1, 2), (144, 48, 3, 1, 13, 64, 1)])
+def test_wgrad_row_variant(ops, case):
+    """opt-in weight-gradient body that runs a kernel row (3 taps) per block: same result as autograd"""
+    from hrseg_amd import _lib
+    cin, cout, k, s, H, W, B = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw = torch.zeros(cout, k * k, cin, device="cuda")
+    _lib.set_wgrad_row(1)
+    try:
+        ops.conv_wgrad(nhwc(x), nhwc(dy), dw, k, s)
+        ops.conv_wgrad_group([nhwc(x), nhwc(x)], [nhwc(dy), nhwc(dy)], [dw, torch.zeros_like(dw)], k, s)
+    finally:
+        _lib.set_wgrad_row(0)
+    assert rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 5e-5
 
 
 def test_conv_into_channel_slice(ops):
