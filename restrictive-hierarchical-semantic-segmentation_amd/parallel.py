@@ -58,6 +58,20 @@ class GradSync:
         self._offsets = None
         self.launched = []          # [(lo, hi)] of the last step, for tests/inspection
         model._grad_hook = self
+        if self.world > 1:
+            self.broadcast_state()
+
+    def broadcast_state(self, src=0):
+        """Replicas must start from identical weights and buffers (what nn.DataParallel's per-step
+        replicate() guarantees in the reference): rank `src`'s flat parameter buffer and every module
+        buffer (BN running statistics) are broadcast once."""
+        m = self.model
+        flat = m.flatten_parameters() if hasattr(m, "flatten_parameters") else getattr(m, "_flat", None)
+        if flat is not None and getattr(flat, "data", None) is not None:
+            dist.broadcast(flat.data, src=src, group=self.group)
+        if hasattr(m, "buffers"):
+            for b in m.buffers():
+                dist.broadcast(b, src=src, group=self.group)
 
     # the model calls this with a mark name while the last backward level runs, then with "end"
     def __call__(self, mark):

@@ -17,8 +17,10 @@ def _fake_model(rank):
     for n, s in zip(names, sizes):
         slots[n] = (off, s)
         off += s
-    flat = types.SimpleNamespace(slots=slots, numel=off, grad=torch.arange(off, dtype=torch.float32) * (rank + 1))
-    return types.SimpleNamespace(_flat=flat, _grad_hook=None)
+    flat = types.SimpleNamespace(slots=slots, numel=off, grad=torch.arange(off, dtype=torch.float32) * (rank + 1),
+                                 data=torch.full((off,), float(rank + 7)))
+    bufs = [torch.full((5,), float(rank)), torch.tensor(rank, dtype=torch.int64)]
+    return types.SimpleNamespace(_flat=flat, _grad_hook=None, buffers=lambda: bufs, _bufs=bufs)
 
 
 def _worker(rank, world, port):
@@ -28,6 +30,9 @@ def _worker(rank, world, port):
     model = _fake_model(rank)
     sync = GradSync(model, min_bucket=1000)
     assert model._grad_hook is sync
+    # construction broadcast rank 0's parameters and buffers
+    assert float(model._flat.data.min()) == float(model._flat.data.max()) == 7.0
+    assert float(model._bufs[0].max()) == 0.0 and int(model._bufs[1]) == 0
     for step in range(2):
         model._flat.grad = torch.arange(model._flat.numel, dtype=torch.float32) * (rank + 1)
         # the reverse pass of the last level crosses the marks in this order
