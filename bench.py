@@ -129,13 +129,13 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE, doubled as the
     gfx950 guide prescribes, + WRITE_SIZE; separate --pmc runs of one full train step, see profiles/README.md).
     Counters cannot be collected from inside this process, so this is the recorded value, or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_traffic_per_launch.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_traffic_per_launch.csv")
     try:
         import csv
         for row in csv.DictReader(open(path)):
             if row["kernel"] == kernel:
                 mb = float(row["FETCH_bytes_MB_corrected_x2"]) + float(row["WRITE_MB"])
-                return round(mb * 2**20), "profiles/r01b_pmc_traffic_per_launch.csv (rocprofv3 --pmc, all fwd+dgrad launches of a step)"
+                return round(mb * 2**20), "profiles/r01d_pmc_traffic_per_launch.csv (rocprofv3 --pmc, all fwd+dgrad launches of a step)"
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -273,6 +273,8 @@ def main():
             line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),
                                           "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4)}
         log("timed: %.3f s for %d steps" % (dt, args.steps))
+        line["config"]["level_passes"] = ("sequential" if getattr(model, "sequential_passes", False) else
+                                          "batched (one launch per layer for all L passes)") if hier else "n/a"
         if world == 1 and hier and graphed is None and not args.no_dedup_line:
             # NOT the headline number: the opt-in mode that runs the L bit-identical level passes once
             # (Models/models.py:_run).  Same result, 1/L of the backbone FLOPs executed -- reported apart.
@@ -293,7 +295,9 @@ def main():
                         "re-execute all L passes as the reference does"}
             log("opt-in dedup passes: %.1f ms/step" % (1e3 * td / args.steps))
         if not args.no_probe:
-            line["roofline"] = probe_dominant_kernel(device, args.batch, args.size)
+            # the level passes run batched: every conv launch sees batch * L images
+            n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1
+            line["roofline"] = probe_dominant_kernel(device, args.batch * n_pass, args.size)
             log("probe: %s" % json.dumps(line["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle train steps, batch 4, on %d cores) ..." % host_cores())

@@ -140,6 +140,10 @@ typedef struct {
   float* z; int ldz;
   float* coef;                                       /* out: [4][C] mean, rstd, scale, shift       */
   double* partial; int nchunks;                      /* scratch nchunks*2*C doubles (training)     */
+  int stat_div;                                      /* training: the tensor holds stat_div identical
+                                                        copies of one pass's images (batched level
+                                                        passes); the unbiased-variance factor uses
+                                                        npix/stat_div (0 or 1 = plain)               */
   int stat_updates;                                  /* training: times the batch statistics enter
                                                         the running averages / num_batches_tracked
                                                         (0 or 1 = once; L = de-duplicated level
@@ -154,7 +158,11 @@ typedef struct {
   float* dy; int lddy;                               /* out (may alias dz)                          */
   float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
   long npix; int C;
-  double* partial; int nchunks;                      /* scratch (nchunks+1)*2*C doubles             */
+  double* partial; int nchunks;                      /* scratch (nchunks+max(nseg,1))*2*C doubles   */
+  int nseg;                                          /* > 1: npix is nseg equal segments (the batched
+                                                        level passes), each normalised on its own: the
+                                                        batch means of the backward are per segment;
+                                                        must divide nchunks and npix (0 or 1 = plain)  */
 } hrseg_bn_bwd_t;
 int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* problems, int eval_mode, hrseg_stream_t stream);
 

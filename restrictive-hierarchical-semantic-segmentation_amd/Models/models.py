@@ -98,7 +98,8 @@ class _Run:
         self.levels = []        # per level dict
         self.probs, self.logits = [], []
         self.done = False
-        self.shared_tape = False   # de-duplicated passes: every level's head hangs off ONE backbone tape
+        self.shared_tape = False   # batched / de-duplicated passes: every level's head hangs off ONE backbone tape
+        self.batched_feats = None  # batched passes: the stacked [L*B,...] feature map the heads slice
 
     def backward(self, dprobs, dlogits):
         m = self.model
@@ -149,10 +150,12 @@ class _Run:
             lv.clear()
         if self.shared_tape and n > 0:
             lv0 = self.levels[0]
-            if lv0["feats"].grad is not None:
+            root = self.batched_feats if self.batched_feats is not None else lv0["feats"]
+            if root.grad is not None:
                 lv0["rec"].backward(m._grad_hook)
             else:
                 lv0["rec"].tape.clear()
+            self.batched_feats = None
             for lv in self.levels:
                 lv.clear()
         # weight gradients ran on the side stream: everything after the reverse pass (all-reduce tail,
@@ -179,6 +182,8 @@ class _EngineModel(nn.Module):
         self._grad_hook = None       # DDP: called with tape marks during the last backward level
         # opt-in: run the L identical level passes of a hierarchical model once (see _run)
         self.dedup_passes = os.environ.get("HRSEG_DEDUP_PASSES", "0") == "1"
+        # run the L training passes one after the other (as the reference does) instead of batched
+        self.sequential_passes = os.environ.get("HRSEG_SEQUENTIAL_PASSES", "0") == "1"
 
     # -- parameters -------------------------------------------------------------------------
     def flatten_parameters(self, device=None):
@@ -230,10 +235,26 @@ class _EngineModel(nn.Module):
         # summation order at 1/L of the backbone work (executed FLOPs change; bench.py reports it apart).
         n_levels = len(self.levels)
         dedup = bool(self.dedup_passes) and self.training and n_levels > 1
-        run.shared_tape = dedup and record
+        # Default in training: the L passes run BATCHED -- the image batch is stacked L times and every layer
+        # is one launch for all passes.  Each pass is still computed in full (same FLOPs as L sequential
+        # passes, same values: batch statistics of L identical copies are those of one pass, the unbiased
+        # variance uses one pass's pixel count, running statistics take L updates, the backward normalises
+        # each pass on its own); it halves the launch count and doubles the work per launch.
+        # `sequential_passes` (HRSEG_SEQUENTIAL_PASSES=1) runs them one after the other as the reference does.
+        batched = self.training and n_levels > 1 and not dedup and not self.sequential_passes
+        run.shared_tape = (dedup or batched) and record
         shared, shared_rec = None, None
+        Bn = x.shape[0]
         for L in range(n_levels):
-            if shared is None:
+            if batched:
+                if shared is None:
+                    rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels)
+                    xx = Act(x_nhwc.data.repeat(n_levels, 1, 1, 1), needs_grad=False)
+                    shared, shared_rec = self._backbone(rec, xx), rec
+                    run.batched_feats = shared
+                feats, rec = Act(shared.data[L * Bn:(L + 1) * Bn]), shared_rec
+                feats.slot = L               # its gradient is rows [L*B, (L+1)*B) of the stacked feature gradient
+            elif shared is None:
                 rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1)
                 feats = self._backbone(rec, x_nhwc)
                 if dedup or (not self.training and not record):
@@ -254,7 +275,7 @@ class _EngineModel(nn.Module):
                     gs = [len(ch) for _, ch in g]
                     groups = (gp, gs)
                     p = ops.compose_fwd(z, run.probs[L - 1], gp, gs)
-            lv.update(rec=rec, groups=groups)
+            lv.update(rec=rec, groups=groups, stacked=run.batched_feats if batched else None)
             run.levels.append(lv)
             run.probs.append(p)
             run.logits.append(z)
@@ -287,12 +308,20 @@ class _EngineModel(nn.Module):
         else:
             dzl = ops.nchw_to_nhwc(dz)
         dgb = ops.zeros(lv["gb"].shape, torch.float32, lv["gb"].device) if film is not None else None
-        g = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
-                         head.bias._hr_gstore, dgb, cout=head.out_channels)
-        if feats.grad is None:
-            feats.grad = g
-        else:                            # shared features (de-duplicated passes): sum over the levels' heads
-            ops.add(feats.grad, g, out=feats.grad)
+        stacked = lv.get("stacked")
+        if stacked is not None:          # batched passes: this level's rows of the stacked feature gradient
+            if stacked.grad is None:
+                stacked.grad = ops.zeros(stacked.data.shape, torch.float32, stacked.data.device)
+            Bn = feats.data.shape[0]
+            ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore, head.bias._hr_gstore,
+                         dgb, df=stacked.grad[feats.slot * Bn:(feats.slot + 1) * Bn], cout=head.out_channels)
+        else:
+            g = ops.head_bwd(feats.data, lv["gb"], head.weight._hr_store, dzl, head.weight._hr_gstore,
+                             head.bias._hr_gstore, dgb, cout=head.out_channels)
+            if feats.grad is None:
+                feats.grad = g
+            else:                        # shared features (de-duplicated passes): sum over the levels' heads
+                ops.add(feats.grad, g, out=feats.grad)
         if film is None:
             return None
         lin = film.mlp[1]

@@ -606,12 +606,17 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
                                            int ldz, int relu, const float* __restrict__ yy, int ldy,
                                            const float* __restrict__ coef, long npix, int C,
                                            double* __restrict__ partial, int chunk, int nchunks, bool bwd,
-                                           double* red) {
+                                           double* red, int nseg = 1) {
   // forward: sums of a0 and a0^2; backward: sums of g and g*xhat with g = a0 * (zmask > 0 if relu)
+  // nseg > 1: the pixel range is nseg equal segments (the batched level passes); a chunk never
+  // straddles two segments (nchunks is a multiple of nseg)
   const Lanes L = make_lanes(C);
-  const long per = (npix + nchunks - 1) / nchunks;
-  const long lo = (long)chunk * per;
-  const long hi = (lo + per < npix) ? lo + per : npix;
+  const int cps = nchunks / nseg, seg = chunk / cps;
+  const long seg_pix = npix / nseg;
+  const long per = (seg_pix + cps - 1) / cps;
+  const long lo = seg * seg_pix + (long)(chunk - seg * cps) * per;
+  const long seg_end = (seg + 1) * seg_pix;
+  const long hi = (lo + per < seg_end) ? lo + per : seg_end;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (L.active) {
     f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f}, sc = mean, sh = mean;
@@ -692,7 +697,11 @@ __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
     p.running_mean[c] = rm;
   }
   if (p.running_var) {
-    const double unb = (p.npix > 1) ? var * (double)p.npix / (double)(p.npix - 1) : var;
+    // stat_div > 1: the tensor holds stat_div identical copies of the pass's images (batched level
+    // passes); mean and biased variance of the copies are those of one pass, the unbiased factor uses
+    // one pass's pixel count
+    const long n1 = p.npix / (p.stat_div > 1 ? p.stat_div : 1);
+    const double unb = (n1 > 1) ? var * (double)n1 / (double)(n1 - 1) : var;
     float rv = p.running_var[c];
     for (int r = 0; r < reps; ++r) rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
     p.running_var[c] = rv;
@@ -734,7 +743,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   __shared__ double red[256 * 8];
   int local, nblk;
   const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
-  stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red);
+  stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
+             p.nseg > 1 ? p.nseg : 1);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
@@ -742,14 +752,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
   int local, nblk;
   const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
   const int C = p.C, c = local * 16 + (threadIdx.x & 15);
-  double s, sx;
-  reduce_chunks16(p.partial, p.nchunks, C, c, s, sx, red);
+  const int nseg = p.nseg > 1 ? p.nseg : 1, cps = p.nchunks / nseg;
+  double* totals = p.partial + (size_t)p.nchunks * 2 * C;      // [nseg][2][C]
+  double s_all = 0.0, sx_all = 0.0;
+  for (int seg = 0; seg < nseg; ++seg) {
+    double s, sx;
+    if (seg) __syncthreads();                                   // red is reused
+    reduce_chunks16(p.partial + (size_t)seg * cps * 2 * C, cps, C, c, s, sx, red);
+    if (threadIdx.x < 16 && c < C) {
+      totals[(size_t)seg * 2 * C + c] = s;
+      totals[(size_t)seg * 2 * C + C + c] = sx;
+      s_all += s;
+      sx_all += sx;
+    }
+  }
   if (threadIdx.x >= 16 || c >= C) return;
-  double* totals = p.partial + (size_t)p.nchunks * 2 * C;
-  totals[c] = s;
-  totals[C + c] = sx;
-  if (p.dgamma) p.dgamma[c] += (float)sx;
-  if (p.dbeta) p.dbeta[c] += (float)s;
+  if (p.dgamma) p.dgamma[c] += (float)sx_all;
+  if (p.dbeta) p.dbeta[c] += (float)s_all;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int eval_mode) {
@@ -761,14 +780,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
   const double* totals = p.partial + (size_t)p.nchunks * 2 * C;
   const f32x4 mean = ld4(p.coef + 4 * L.cq), rstd = ld4(p.coef + C + 4 * L.cq), scale = ld4(p.coef + 2 * C + 4 * L.cq);
   const f32x4 shift = ld4(p.coef + 3 * C + 4 * L.cq);
+  const int nseg = p.nseg > 1 ? p.nseg : 1;
+  const long seg_pix = p.npix / nseg;
+  const float inv = eval_mode ? 0.f : (float)(1.0 / (double)seg_pix);
+  for (int seg = 0; seg < nseg; ++seg) {
   f32x4 mg, mgx;
-  const float inv = eval_mode ? 0.f : (float)(1.0 / (double)p.npix);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    mg[j] = (float)(totals[4 * L.cq + j]) * inv;
-    mgx[j] = (float)(totals[C + 4 * L.cq + j]) * inv;
+    mg[j] = (float)(totals[(size_t)seg * 2 * C + 4 * L.cq + j]) * inv;
+    mgx[j] = (float)(totals[(size_t)seg * 2 * C + C + 4 * L.cq + j]) * inv;
   }
-  for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
+  for (long pix = seg * seg_pix + (long)local * L.P + L.pl; pix < (seg + 1) * seg_pix; pix += (long)nblk * L.P) {
     f32x4 gg = ld4(p.dz + pix * p.lddz + 4 * L.cq);
     const f32x4 yv = ld4(p.y + pix * p.ldy + 4 * L.cq);
     if (p.relu) {
@@ -782,6 +804,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
       float* d = p.dres + pix * p.lddres + 4 * L.cq;
       st4(d, p.dres_accumulate ? ld4(d) + gg : gg);
     }
+  }
   }
 }
 
@@ -1069,6 +1092,8 @@ extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_m
     if (int e = check_c(p.C, "hrseg_bn_bwd_group")) return e;
     HRSEG_CHECK_ARG(p.dz && p.y && p.coef && p.dy && p.partial && p.npix > 0 && p.nchunks > 0,
                     "hrseg_bn_bwd_group: bad arguments");
+    HRSEG_CHECK_ARG(p.nseg <= 1 || (p.nchunks % p.nseg == 0 && p.npix % p.nseg == 0),
+                    "hrseg_bn_bwd_group: nseg=%d must divide nchunks=%d and npix", p.nseg, p.nchunks);
     g.p[i] = p;
   }
   int end = 0;

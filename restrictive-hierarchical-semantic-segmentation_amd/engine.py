@@ -45,7 +45,7 @@ def wgrad_stream(device):
 
 class Act:
     """An activation and its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "slot")
 
     def __init__(self, data, needs_grad=True):
         self.data = data
@@ -157,10 +157,11 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None, bn_repeat=1):
+    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1):
         self.training = training
         self.record = record
-        self.bn_repeat = bn_repeat   # running-stat updates per BN (de-duplicated level passes)
+        self.bn_repeat = bn_repeat       # running-stat updates per BN (level passes run as one)
+        self.bn_segments = bn_segments   # the batch holds this many level passes of the same images (batched passes)
         self.tape = []
         self.flat = flat
         self.wt_cache = {}
@@ -225,6 +226,7 @@ class Recorder:
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
                          residual=res.data if res is not None else None, relu=relu, repeat=self.bn_repeat,
+                         stat_div=self.bn_segments,
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
         zc = ops.bn_fwd_group(bn_items, self.training)
@@ -249,7 +251,7 @@ class Recorder:
                 # without a residual the ReLU mask is recomputed from y: the backward never reads z
                 bw.append(dict(dz=dz, z=z.data if (relu and res is not None) else None, relu=relu, y=y, coef=coef,
                                dgamma=bn.weight._hr_gstore,
-                               dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc))
+                               dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments))
             dys = ops.bn_bwd_group(bw, eval_mode)
             need = [i for i, x in enumerate(xs) if x.needs_grad]
             side = wgrad_stream(dys[0].device)

@@ -216,6 +216,7 @@ def bn_fwd_group(items, training):
         a.num_batches_tracked = ptr(it["nbt"]) if training else None
         a.momentum, a.eps = float(it["momentum"]), float(it["eps"])
         a.stat_updates = int(it.get("repeat", 1))
+        a.stat_div = int(it.get("stat_div", 1))
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         if training:
@@ -239,9 +240,13 @@ def bn_bwd_group(items, eval_mode):
     for a, it in zip(arr, items):
         y, dz, z = it["y"], it["dz"], it["z"]
         Cn, npix = y.shape[3], _npix(y)
+        nseg = int(it.get("nseg", 1))
         nch = _nchunks(npix, Cn)
-        part = torch.empty((nch + 1) * 2 * Cn, dtype=torch.float64, device=y.device)
+        if nseg > 1:                                  # chunks never straddle two segments
+            nch = max(nseg, nch // nseg * nseg)
+        part = torch.empty((nch + nseg) * 2 * Cn, dtype=torch.float64, device=y.device)
         keep.append(part)
+        a.nseg = nseg
         dres = it.get("dres")
         a.dz, a.lddz = ptr(dz), _ld(dz)
         use_z = it["relu"] and z is not None      # z None: mask recomputed from y (forward without residual)

@@ -242,7 +242,7 @@ def test_train_epoch_and_test_loops_run():
 
 
 @pytest.mark.parametrize("name", ["unet_hier_ext_32", "hrnet_hier_tl_64"])
-def test_dedup_passes_equals_faithful_passes(name):
+def test_batched_and_dedup_passes_equal_sequential_passes(name):
     """opt-in `dedup_passes`: one backbone pass + L running-stat updates + summed head gradients must give
     what the L faithfully re-executed passes give: logits, loss, BN buffers (incl. num_batches_tracked = L)
     and every parameter gradient (fp32 summation order is the only difference)."""
@@ -257,9 +257,10 @@ def test_dedup_passes_equals_faithful_passes(name):
     weights = level_weights_for(tree_file, hier)
     args = _args(kind, hier, num_classes, weights, batch)
     results = []
-    for dedup in (False, True, False):
+    for mode in ("sequential", "dedup", "sequential", "batched"):
         model = build_model(PM, kind, hier, tree, size).cuda()
-        model.dedup_passes = dedup
+        model.dedup_passes = mode == "dedup"
+        model.sequential_passes = mode == "sequential"
         model.train()
         probs, logits = PT._model_call(model, x, args, tree)
         targets = PT.split_targets(target, args)
@@ -272,7 +273,7 @@ def test_dedup_passes_equals_faithful_passes(name):
         results.append(dict(logits=[z.detach().cpu().numpy() for z in logits], loss=float(loss),
                             grads={n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()},
                             bufs={n: b.detach().cpu().numpy() for n, b in model.named_buffers()}))
-    ref, ded, ref2 = results          # ref2: a second faithful run = the run-to-run noise of the atomics
+    ref, ded, ref2, bat = results     # ref2: a second sequential run = the run-to-run noise of the atomics
     assert abs(ref["loss"] - ded["loss"]) < 1e-5 * max(1.0, abs(ref["loss"]))
     for a, b in zip(ref["logits"], ded["logits"]):
         assert rel_err(b, a) < 1e-5
@@ -300,6 +301,22 @@ def test_dedup_passes_equals_faithful_passes(name):
     med = np.median([rel_err(ded["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     noise = np.median([rel_err(ref2["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     assert med < max(3e-3, 4 * noise), (med, noise)
+
+    # the default execution: the L passes batched into one launch per layer -- same checks
+    assert abs(ref["loss"] - bat["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    # (other tile plans / split-K choices at L*B images and other statistics chunking reorder fp32 sums)
+    for a, b in zip(ref["logits"], bat["logits"]):
+        assert rel_err(b, a) < 1e-4
+    for n, b in ref["bufs"].items():
+        if n.endswith("num_batches_tracked"):
+            assert int(bat["bufs"][n]) == n_levels, n
+        else:
+            assert rel_err(bat["bufs"][n], b) < 1e-4, n
+    worst_b, worst_b_name = worst_of(bat)
+    med_b = np.median([rel_err(bat["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
+    print(f"batched vs sequential: worst {worst_b:.3e} ({worst_b_name}), median {med_b:.3e}")
+    assert worst_b < max(1e-1, 4 * worst_noise), (worst_b, worst_b_name, worst_noise)
+    assert med_b < max(3e-3, 4 * noise), (med_b, noise)
 
 
 def test_full_size_step_properties():
