@@ -291,8 +291,8 @@ def main():
             line["opt_in_dedup_passes"] = {
                 "value": round(args.batch * args.steps / td, 3), "unit": "images/s",
                 "ms_per_step": round(1e3 * td / args.steps, 2), "executed_backbone_passes_per_step": 1,
-                "note": "explicit opt-in (model.dedup_passes / HRSEG_DEDUP_PASSES=1); default and headline value "
-                        "re-execute all L passes as the reference does"}
+                "note": "explicit opt-in (model.dedup_passes / HRSEG_DEDUP_PASSES=1); the default and headline value "
+                        "execute all L passes"}
             log("opt-in dedup passes: %.1f ms/step" % (1e3 * td / args.steps))
         if not args.no_probe:
             # the level passes run batched: every conv launch sees batch * L images
