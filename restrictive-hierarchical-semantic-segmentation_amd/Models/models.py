@@ -77,7 +77,10 @@ class _Bridge(torch.autograd.Function):
         run = model._run(x, record)
         ctx.run = run if record else None
         ctx.set_materialize_grads(False)
-        outs = tuple(run.probs) + tuple(run.logits)
+        # return ALIASES: autograd stamps its grad_fn on the returned objects, and grad_fn -> ctx.run ->
+        # run.probs would otherwise close a reference cycle through the C++ node that no collector breaks
+        # (the step then retains its logits/probabilities for ever)
+        outs = tuple(t.detach() for t in run.probs) + tuple(t.detach() for t in run.logits)
         ctx.n_probs = len(run.probs)
         return outs
 
@@ -168,6 +171,7 @@ class _Run:
         if m._grad_hook is not None:
             m._grad_hook("end")
         self.levels = []
+        self.probs, self.logits = [], []
         self.done = True
 
 

@@ -120,6 +120,10 @@ def set_wgrad_row(on=1):
     _lib.hrseg_debug_set_wgrad_row(int(on))
 
 
+_lib.hrseg_debug_set_group_wtm.restype = _i
+_lib.hrseg_debug_set_group_wtm.argtypes = [_i]
+if "HRSEG_GROUP_WTM" in os.environ:          # A/B switch for tuning runs
+    _lib.hrseg_debug_set_group_wtm(int(os.environ["HRSEG_GROUP_WTM"]))
 if "HRSEG_WGRAD_ROW" in os.environ:          # A/B switch for tuning runs
     set_wgrad_row(int(os.environ["HRSEG_WGRAD_ROW"]))
 

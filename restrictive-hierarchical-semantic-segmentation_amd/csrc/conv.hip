@@ -577,6 +577,9 @@ static int dispatch_patch(const IgemmArgs& a, int flip, hipStream_t st) {
 // group dispatch: one common plan (64-pixel tiles, widest K stage, single LDS buffer); problems whose
 // channel tiling differs from the first one's, or that need a zero-fill they cannot get, make the
 // caller fall back to per-problem launches (return 1).
+static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
+extern "C" int hrseg_debug_set_group_wtm(int wtm) { g_group_wtm = wtm; return 0; }
+
 static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
   const int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
@@ -589,8 +592,9 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
   // per-problem split-K, then order the problems by stages per block, longest first: the blocks
   // that run longest must not be the ones dispatched last (the grid's tail)
   int tiles[MAXG], ks[MAXG], work[MAXG], order[MAXG];
+  const int wtm = g_group_wtm ? g_group_wtm : 1;
   for (int i = 0; i < n; ++i) {
-    tiles[i] = ceil_div(a[i].M, 64) * (a[i].N / (16 * wtn));
+    tiles[i] = ceil_div(a[i].M, 64 * wtm) * (a[i].N / (16 * wtn));
     const int nstages = a[i].ntaps * (a[i].K / (16 * kc));
     ks[i] = 1;
     const bool can_split = a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1);
@@ -616,7 +620,10 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
     g.a[o] = a[i];
     if (finalize_args(g.a[o])) return 1;   // per-problem launches report the error
   }
-  if (wtn == 3 && kc == 3) launch_igemm_group<1, 3, 3, 1>(g, st);
+  if (wtm == 2 && wtn == 3 && kc == 3) launch_igemm_group<2, 3, 3, 1>(g, st);
+  else if (wtm == 2 && wtn == 3) launch_igemm_group<2, 3, 1, 1>(g, st);
+  else if (wtm == 2) return 1;
+  else if (wtn == 3 && kc == 3) launch_igemm_group<1, 3, 3, 1>(g, st);
   else if (wtn == 3 && kc == 2) launch_igemm_group<1, 3, 2, 1>(g, st);
   else if (wtn == 3) launch_igemm_group<1, 3, 1, 1>(g, st);
   else if (kc == 3) launch_igemm_group<1, 4, 3, 1>(g, st);

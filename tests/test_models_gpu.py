@@ -432,3 +432,34 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     for i in some:
         p = list(pm2.parameters())[i]
         assert torch.equal(pm2.flatten_parameters().view_of(popt3._m, p).cpu(), st[i]["exp_avg"])
+
+
+def test_train_steps_do_not_retain_memory():
+    """a step must not keep its logits/probabilities alive (reference cycle through the autograd node)"""
+    import gc
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    kind, hier, tree_file, size, batch = CASES["unet_hier_tl_62"]
+    g = load_golden("unet_hier_tl_62")
+    tree = load_tree(tree_file)
+    num_classes = [int(v) for v in g["num_classes"]]
+    args = _args(kind, hier, num_classes, level_weights_for(tree_file, hier), batch)
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    model = build_model(PM, kind, hier, tree, size).cuda()
+    opt = PT.FusedAdamW(model, lr=[1e-4])
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in num_classes]
+    model.train()
+    ll, seen = [], []
+    for step in range(6):
+        PT.train_step(model, opt, x, target, fns, args, tree, ll)
+        torch.cuda.synchronize()
+        gc.collect()
+        seen.append(torch.cuda.memory_allocated())
+    assert seen[2] == seen[3] == seen[4] == seen[5], seen
+    # forward without a backward (e.g. a validation loss under grad mode) is released as well
+    for _ in range(3):
+        PT._model_call(model, x, args, tree)
+        gc.collect()
+        seen.append(torch.cuda.memory_allocated())
+    assert seen[-1] == seen[-2] == seen[5], seen
