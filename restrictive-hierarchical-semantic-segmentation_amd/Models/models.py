@@ -179,6 +179,7 @@ class _EngineModel(nn.Module):
     """Shared level loop (reference models.py:257-306 / :751-802) over an engine backbone."""
 
     align_corners = True
+    batch_passes_by_default = True
 
     def _init_engine(self):
         self._flat = None
@@ -187,7 +188,9 @@ class _EngineModel(nn.Module):
         # opt-in: run the L identical level passes of a hierarchical model once (see _run)
         self.dedup_passes = os.environ.get("HRSEG_DEDUP_PASSES", "0") == "1"
         # run the L training passes one after the other (as the reference does) instead of batched
-        self.sequential_passes = os.environ.get("HRSEG_SEQUENTIAL_PASSES", "0") == "1"
+        # (default per model: HRNet's many small layers gain 12 % from batching, UNet's few large ones nothing)
+        env = os.environ.get("HRSEG_SEQUENTIAL_PASSES")
+        self.sequential_passes = (env == "1") if env is not None else not self.batch_passes_by_default
 
     # -- parameters -------------------------------------------------------------------------
     def flatten_parameters(self, device=None):
@@ -385,6 +388,7 @@ class outconv(nn.Module):
 
 class UNet(_EngineModel):
     """Flat (type==0): returns [], logits.  Hierarchical (type==1): level loop with FiLM."""
+    batch_passes_by_default = False     # measured: 84.8 ms batched vs 83.2 ms sequential (hier, 620x620, B=4)
 
     def __init__(self, size=620, n_channels=1, hierarchy={}, model_type=0):
         super().__init__()
