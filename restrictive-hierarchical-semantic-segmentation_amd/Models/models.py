@@ -580,41 +580,32 @@ class HighResolutionModule(nn.Module):
             return [_run_seq(rec, self.branches[0], xs[0])]
         xs = self._run_branches(rec, xs)
         nb = self.num_branches
-        # every first step of the fuse paths only needs the branch outputs: issue them as grouped
-        # launches (1x1 convs of the up paths; stride-2 3x3 convs of the down chains, level by level)
-        # (a group must not hold two consumers of the same tensor: their data gradients would race
-        # into one buffer -- so groups are formed per output row i, where the sources j differ)
+        # every first step of the fuse paths only needs the branch outputs: ALL 1x1 convs of the up paths are
+        # one grouped launch, the stride-2 3x3 convs of the down chains one grouped launch per chain depth
+        # (ReLU per item: every conv of a chain but its last).  Several paths read the same branch output;
+        # the engine issues their data gradients in rounds of distinct inputs.
+        nf = len(self.fuse_layers)
         term = {}
-        for i in range(len(self.fuse_layers)):
-            chunk = [(i, j) for j in range(nb) if j > i]
-            if not chunk:
-                continue
+        ups = [(i, j) for i in range(nf) for j in range(nb) if j > i]
+        for c0 in range(0, len(ups), 8):
+            chunk = ups[c0:c0 + 8]
             outs_ = rec.conv_bn_group([(xs[j], self.fuse_layers[i][j][0], self.fuse_layers[i][j][1], None)
                                        for i, j in chunk], relu=False)
-            for (i, j), o in zip(chunk, outs_):
-                term[(i, j)] = o
-        chains = {(i, j): xs[j] for i in range(len(self.fuse_layers)) for j in range(nb) if j < i}
+            for key, o in zip(chunk, outs_):
+                term[key] = o
+        chains = {(i, j): xs[j] for i in range(nf) for j in range(nb) if j < i}
         depth = 0
         while True:
             live = [(i, j) for (i, j) in chains if len(self.fuse_layers[i][j]) > depth]
             if not live:
                 break
-            for want_relu in (True, False):
-                sel = [(i, j) for (i, j) in live if (len(self.fuse_layers[i][j][depth]) == 3) == want_relu]
-                # depth 0 reads the branch outputs (shared between rows): one group per row i;
-                # deeper steps read chain-private tensors and may be grouped freely
-                if depth == 0:
-                    chunks = [[(i, j) for (i, j) in sel if i == ii] for ii in range(len(self.fuse_layers))]
-                else:
-                    chunks = [sel[c0:c0 + 4] for c0 in range(0, len(sel), 4)]
-                for chunk in chunks:
-                    if not chunk:
-                        continue
-                    outs_ = rec.conv_bn_group([(chains[(i, j)], self.fuse_layers[i][j][depth][0],
-                                                self.fuse_layers[i][j][depth][1], None) for i, j in chunk],
-                                              relu=want_relu)
-                    for key, o in zip(chunk, outs_):
-                        chains[key] = o
+            for c0 in range(0, len(live), 8):
+                chunk = live[c0:c0 + 8]
+                outs_ = rec.conv_bn_group([(chains[(i, j)], self.fuse_layers[i][j][depth][0],
+                                            self.fuse_layers[i][j][depth][1], None) for i, j in chunk],
+                                          relu=[len(self.fuse_layers[i][j][depth]) == 3 for i, j in chunk])
+                for key, o in zip(chunk, outs_):
+                    chains[key] = o
             depth += 1
         outs = []
         for i in range(len(self.fuse_layers)):

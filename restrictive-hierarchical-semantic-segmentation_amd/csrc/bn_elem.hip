@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 // into the statistics kernel -- last block to finish reduces the partials -- was measured 2-3x SLOWER:
 // one block reading up to 600 KB of cold partials takes 30-60 us against 7 us for the C/16-block
 // finalize launch, and a device-scope fence per block costs L2 write-backs.)
-#define BN_MAXG 4
+#define BN_MAXG 8
 struct BnGroupHdr { int n; int blk_end[BN_MAXG]; };
 __device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nblk) {
   int g = 0;

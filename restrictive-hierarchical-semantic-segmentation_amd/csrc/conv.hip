@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
 
 // Several independent convolutions (the parallel HRNet branches) in ONE grid: block ranges
 // [blk_end[g-1], blk_end[g]) belong to problem g, each with its own tile count and split-K factor.
-#define MAXG 4
+#define MAXG 8
 struct IgemmGroup {
   int n;
   int blk_end[MAXG];

@@ -15,6 +15,7 @@ in-place accumulation is always safe.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -208,13 +209,15 @@ class Recorder:
 
     def conv_bn_group(self, items, relu, outs=None):
         """items: list of (x, conv, bn, residual-or-None), independent of each other (the parallel
-        HRNet branches; a single layer is a group of one).  Per group: one conv launch, three BN
-        launches; backward: three BN launches, one wgrad launch, one dgrad launch."""
+        HRNet branches, the fuse paths of a module; a single layer is a group of one); relu: one flag or
+        one per item.  Per group: one conv launch, three BN launches; backward: three BN launches, one
+        wgrad launch and one dgrad launch per round of problems with DISTINCT inputs (two problems
+        that read the same tensor must not write its gradient in one launch)."""
         n = len(items)
+        relus = list(relu) if isinstance(relu, (list, tuple)) else [relu] * n
         k, s = items[0][1].kernel_size[0], items[0][1].stride[0]
         assert all(c.kernel_size[0] == k and c.stride[0] == s for _, c, _, _ in items)
         xs = [it[0] for it in items]
-        assert len({id(x) for x in xs}) == n, "a group must not read one tensor twice (data gradients would race)"
         if n == 1:
             conv = items[0][1]
             ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
@@ -225,7 +228,7 @@ class Recorder:
                                     [c.out_channels for _, c, _, _ in items])
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
-                         residual=res.data if res is not None else None, relu=relu, repeat=self.bn_repeat,
+                         residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
                          stat_div=self.bn_segments,
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
@@ -238,7 +241,7 @@ class Recorder:
 
         def bwd():
             bw = []
-            for (x, conv, bn, res), y, z, coef in zip(items, ys, zs, coefs):
+            for i, ((x, conv, bn, res), y, z, coef) in enumerate(zip(items, ys, zs, coefs)):
                 dz = z.grad
                 z.grad = None
                 dres, dres_acc = None, False
@@ -249,44 +252,45 @@ class Recorder:
                         dres_acc = True
                     dres = res.grad
                 # without a residual the ReLU mask is recomputed from y: the backward never reads z
-                bw.append(dict(dz=dz, z=z.data if (relu and res is not None) else None, relu=relu, y=y, coef=coef,
+                bw.append(dict(dz=dz, z=z.data if (relus[i] and res is not None) else None, relu=relus[i], y=y, coef=coef,
                                dgamma=bn.weight._hr_gstore,
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments))
             dys = ops.bn_bwd_group(bw, eval_mode)
-            need = [i for i, x in enumerate(xs) if x.needs_grad]
             side = wgrad_stream(dys[0].device)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    if n == 1:
-                        ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s)
-                    else:
-                        ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items],
-                                             k, s)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if n == 1:
+                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s)
+                else:
+                    ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
+            if side is not None:
                 for t in dys:
                     t.record_stream(side)     # not reused before the side stream is done reading it
                 for x in xs:
                     x.data.record_stream(side)
                 self.used_side = True
-            if n == 1:
-                conv = items[0][1]
-                if side is None:
-                    ops.conv_wgrad(xs[0].data, dys[0], conv.weight._hr_gstore, k, s)
-                if need:
-                    x = xs[0]
+            # data gradients: rounds of problems whose inputs are distinct tensors
+            todo = [i for i, x in enumerate(xs) if x.needs_grad]
+            while todo:
+                seen, rnd, rest = set(), [], []
+                for i in todo:
+                    (rest if id(xs[i]) in seen else rnd).append(i)
+                    seen.add(id(xs[i]))
+                if len(rnd) == 1:
+                    i = rnd[0]
+                    x = xs[i]
                     if x.grad is None:
-                        x.grad = ops.conv_dgrad(dys[0], self._wt(conv), x.data.shape, k, s)
+                        x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s)
                     else:
-                        ops.conv_dgrad(dys[0], self._wt(conv), x.data.shape, k, s, out=x.grad, accumulate=True)
-                return
-            if side is None:
-                ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
-            if need:
-                got = ops.conv_dgrad_group([dys[i] for i in need], [self._wt(items[i][1]) for i in need],
-                                           [xs[i].data.shape for i in need], k, s, [xs[i].grad for i in need],
-                                           [xs[i].grad is not None for i in need])
-                for i, o in zip(need, got):
-                    xs[i].grad = o
+                        ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, out=x.grad, accumulate=True)
+                else:
+                    got = ops.conv_dgrad_group([dys[i] for i in rnd], [self._wt(items[i][1]) for i in rnd],
+                                               [xs[i].data.shape for i in rnd], k, s, [xs[i].grad for i in rnd],
+                                               [xs[i].grad is not None for i in rnd])
+                    for i, o in zip(rnd, got):
+                        xs[i].grad = o
+                todo = rest
         self._push(bwd)
         return zs
 
