@@ -1486,6 +1486,9 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
     return 0;
   }
   // stride 2: dx[y,x] = sum_{kh,kw : (y+pad-kh) even, (x+pad-kw) even} dy[(y+pad-kh)/2, (x+pad-kw)/2] w[kh,kw]
+  // The four output-parity classes write disjoint pixels of dx: one grouped launch.
+  IgemmArgs cls[4];
+  int ncls = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int hc = (s->Hi - py + 1) / 2, wc = (s->Wi - px + 1) / 2;  // pixels of this parity class
@@ -1504,9 +1507,16 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
       c.Ho = hc; c.Wo = wc; c.M = s->B * hc * wc;
       c.sy = c.sx = 1; c.oys = c.oxs = 2; c.oy0 = py; c.ox0 = px;
       pack_taps(c, n, oy, ox, wtp);
-      if (int e = dispatch_igemm(c, st)) return e;
-      HRSEG_LAUNCH_CHECK("igemm_conv(dgrad s2)");
+      cls[ncls++] = c;
     }
+  if (ncls >= 2 && dispatch_igemm_group(cls, ncls, st) == 0) {
+    HRSEG_LAUNCH_CHECK("igemm_group(dgrad s2)");
+    return 0;
+  }
+  for (int i = 0; i < ncls; ++i) {
+    if (int e = dispatch_igemm(cls[i], st)) return e;
+    HRSEG_LAUNCH_CHECK("igemm_conv(dgrad s2)");
+  }
   return 0;
 }
 
