@@ -117,8 +117,8 @@ def probe_dominant_kernel(device, batch, size):
     ms = e0.elapsed_time(e1) / (reps * launches)
     flops = sum(sum(fl[:n]) * r for n, r in mix) / launches
     ach = flops / (ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic("igemm_group_kernel<1, 3, 3, 1>")
-    return {"bound": "mfma", "kernel": "igemm_group_kernel<1,3,3,1> (3x3 branch convs 48/96/192/384 ch at %s, B=%d; "
+    traffic, traffic_src = pmc_traffic("igemm_group_kernel<1, 3, 3, 1, true>")
+    return {"bound": "mfma", "kernel": "igemm_group_kernel<1,3,3,1,true> (3x3 branch convs 48/96/192/384 ch at %s, B=%d; "
                                        "stage-2/3/4 mix of one backbone pass)" % ("/".join(str(h) for h in sizes), batch),
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)",
@@ -129,13 +129,13 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE, doubled as the
     gfx950 guide prescribes, + WRITE_SIZE; separate --pmc runs of one full train step, see profiles/README.md).
     Counters cannot be collected from inside this process, so this is the recorded value, or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_traffic_per_launch.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic_per_launch.csv")
     try:
         import csv
         for row in csv.DictReader(open(path)):
             if row["kernel"] == kernel:
                 mb = float(row["FETCH_bytes_MB_corrected_x2"]) + float(row["WRITE_MB"])
-                return round(mb * 2**20), "profiles/r01d_pmc_traffic_per_launch.csv (rocprofv3 --pmc, all fwd+dgrad launches of a step)"
+                return round(mb * 2**20), "profiles/r01e_pmc_traffic_per_launch.csv (rocprofv3 --pmc, all fwd+dgrad launches of a step)"
     except (OSError, KeyError, ValueError):
         pass
     return None, None

@@ -284,7 +284,10 @@ struct IgemmGroup {
   int ksplit[MAXG];
   IgemmArgs a[MAXG];
 };
-template <int WTM, int WTN, int KC, int DB>
+// FULL3X3 is a call-site tag only (same code): groups of full 3x3 stride-1 problems -- the parallel branch
+// convs, forward and data-gradient, the dominant launches of a step -- get their own kernel symbol, so
+// profiles list them apart from the small fuse-path / parity-class groups.
+template <int WTM, int WTN, int KC, int DB, bool FULL3X3>
 __global__ __launch_bounds__(256) void igemm_group_kernel(IgemmGroup grp) {
   __shared__ __attribute__((aligned(16))) float lds[DB * (64 * WTM + 16 * WTN) * 16 * KC];
   int g = 0;
@@ -302,7 +305,10 @@ static void launch_igemm(const IgemmArgs& a, int ksplit, hipStream_t st) {
 }
 template <int WTM, int WTN, int KC, int DB>
 static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
-  hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
+  bool full = true;
+  for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
+  if (full) hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, true>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, false>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
 }
 
 // debug/tuning override (0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
