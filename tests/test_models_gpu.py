@@ -463,3 +463,39 @@ def test_train_steps_do_not_retain_memory():
         gc.collect()
         seen.append(torch.cuda.memory_allocated())
     assert seen[-1] == seen[-2] == seen[5], seen
+
+
+@pytest.mark.parametrize("kind,H,W,B", [("unet", 50, 66, 3), ("hrnet", 70, 44, 1), ("hrnet", 36, 100, 3)])
+def test_ragged_shapes_against_the_oracle(kind, H, W, B):
+    """non-square, odd-quarter sizes and batch 1/3 (floor/pad paths of UNet, odd HRNet branch sizes, the
+    batched level passes at an odd batch): train-mode logits, loss and eval-mode logits against the oracle"""
+    from oracle import models as OM
+    from oracle import losses as OL
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd.utils import synth
+    tree = load_tree("class_tree_tl.json")
+    weights = level_weights_for("class_tree_tl.json", True)
+    g = np.random.Generator(np.random.PCG64(H * W + B))
+    x = torch.from_numpy(g.standard_normal((B, 3, H, W)).astype(np.float32))
+    lab = g.integers(0, 7, size=(B, H, W))
+    target = torch.from_numpy(synth.encode_targets(lab, tree, True))
+    om = build_model(OM, kind, True, tree, max(H, W))
+    pm = build_model(PM, kind, True, tree, max(H, W)).cuda()
+    om.train(), pm.train()
+    _, zo = om(x, type=1) if kind == "unet" else om(x)
+    _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
+    lo = lp = 0.0
+    for L, (a, b) in enumerate(zip(zo, zp)):
+        assert rel_err(b.detach().cpu().numpy(), a.detach().numpy()) < TOL, f"train logits {L}"
+        t = target[:, 4 * L:4 * L + 4]
+        lo = lo + OL.cross_entropy_loss(a, t, logits_input=True, class_weight=weights[L])
+        ce, dice = PL.fused_ce_dice(b, t.cuda(), weights[L])[:2]
+        lp = lp + ce
+    assert abs(float(lp) - float(lo)) < TOL * max(1.0, abs(float(lo)))
+    om.eval(), pm.eval()
+    with torch.no_grad():
+        _, zo = om(x, type=1) if kind == "unet" else om(x)
+        _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
+    for L, (a, b) in enumerate(zip(zo, zp)):
+        assert rel_err(b.cpu().numpy(), a.numpy()) < TOL, f"eval logits {L}"
