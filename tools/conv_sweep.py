@@ -6,7 +6,7 @@ import torch
 from hrseg_amd import ops, _lib
 
 PEAK = 157.3
-B = 4
+B = int(os.environ.get("SWEEP_B", "4"))
 SHAPES = [
     ("hr 48->48 3x3 @155", 48, 48, 3, 1, 155), ("hr 96->96 3x3 @78", 96, 96, 3, 1, 78),
     ("hr 192->192 3x3 @39", 192, 192, 3, 1, 39), ("hr 384->384 3x3 @20", 384, 384, 3, 1, 20),
