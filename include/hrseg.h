@@ -141,6 +141,11 @@ typedef struct {
   float* z; int ldz;
   float* coef;                                       /* out: [4][C] mean, rstd, scale, shift       */
   double* partial; int nchunks;                      /* scratch nchunks*2*C doubles (training)     */
+  double* acc; int* counter;                         /* optional one-launch statistics: acc = 2*C
+                                                        doubles, counter = one int, both ZERO before
+                                                        the first use; the kernels leave them zero, so
+                                                        one workspace serves every later call on a
+                                                        stream.  NULL: partial + a finalize launch    */
   int stat_div;                                      /* training: the tensor holds stat_div identical
                                                         copies of one pass's images (batched level
                                                         passes); the unbiased-variance factor uses
@@ -160,6 +165,8 @@ typedef struct {
   float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
   long npix; int C;
   double* partial; int nchunks;                      /* scratch (nchunks+max(nseg,1))*2*C doubles   */
+  double* acc; int* counter;                         /* as in hrseg_bn_fwd_t, acc = max(nseg,1)*2*C
+                                                        doubles; NULL: partial + a finalize launch    */
   int nseg;                                          /* > 1: npix is nseg equal segments (the batched
                                                         level passes), each normalised on its own: the
                                                         batch means of the backward are per segment;

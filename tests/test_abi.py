@@ -43,7 +43,7 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in _lib.PROTOTYPES:
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == 3
+    assert _lib.abi_version() == 4
 
 
 def test_invalid_arguments_are_reported_without_a_gpu():

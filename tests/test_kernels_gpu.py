@@ -155,10 +155,13 @@ def test_batchnorm_eval_coef(ops):
     assert rel(nchw(z), F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)) < 1e-5
 
 
-def test_batchnorm_group_fwd_bwd(ops):
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_batchnorm_group_fwd_bwd(ops, one_launch, monkeypatch):
     """grouped BN (statistics, finalize, apply; reduce, totals, apply): four problems of different size per
     launch, run twice, with and without residual; without residual the backward gets no z and recomputes
     the ReLU mask from y"""
+    # one_launch: statistics accumulated with fp64 atomics, finalize by the last block (opt-in HRSEG_BN_ONE_LAUNCH)
+    monkeypatch.setattr(ops, "BN_ONE_LAUNCH", one_launch)
     cfgs = [(48, 37, 41, 2, True), (96, 19, 20, 2, False), (384, 5, 6, 2, False), (192, 9, 9, 3, True)]
     g = torch.Generator().manual_seed(7)
     probs = []
