@@ -249,8 +249,8 @@ class _EngineModel(nn.Module):
         # each pass on its own); it halves the launch count and doubles the work per launch.
         # `sequential_passes` (HRSEG_SEQUENTIAL_PASSES=1) runs them one after the other as the reference does.
         batched = (self.training and n_levels > 1 and not dedup and not self.sequential_passes
-                   # the kernels index up to 2^24 pixels per tensor: larger stacks run the passes sequentially
-                   and n_levels * x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24))
+                   # 32-bit pixel indices in the kernels: larger stacks run the passes sequentially
+                   and n_levels * x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31))
         run.shared_tape = (dedup or batched) and record
         shared, shared_rec = None, None
         Bn = x.shape[0]

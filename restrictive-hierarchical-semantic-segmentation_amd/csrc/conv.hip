@@ -39,8 +39,10 @@ struct IgemmArgs {
   int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
 };
 
-// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction)
+// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for
+// tensors of 2^24 pixels or more) selects the plain integer division
 __device__ __forceinline__ int fdiv(int n, int d, float rcp) {
+  if (rcp <= 0.f) return n / d;
   int q = (int)((float)n * rcp);
   const int r = n - q * d;
   q += (r >= d) ? 1 : 0;
@@ -368,8 +370,9 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
 // derived fields + the host-side check behind the kernels' 32-bit buffer offsets: a tile (<= 256 GEMM
 // rows) touches at most ceil(256 / (Ho*Wo)) + 1 consecutive images, which must span < 4 GB
 static int finalize_args(IgemmArgs& a) {
-  a.rcp_hw = 1.0f / (float)(a.Ho * a.Wo);
-  a.rcp_w = 1.0f / (float)a.Wo;
+  const bool big = (long)a.B * a.Ho * a.Wo >= (1L << 24);      // float-reciprocal division is exact below 2^24
+  a.rcp_hw = big ? 0.f : 1.0f / (float)(a.Ho * a.Wo);
+  a.rcp_w = big ? 0.f : 1.0f / (float)a.Wo;
   a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
   const double span = ((double)ceil_div(256, a.Ho * a.Wo) + 1.0) * a.Hi * a.Wi * (double)a.ldx * 4.0;
   const double wbytes = (double)a.N * a.T * a.K * 4.0;
@@ -1300,8 +1303,8 @@ static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(ho == s->Ho && wo == s->Wo, "%s: output %dx%d does not match input %dx%d k%d s%d (expect %dx%d)",
                   who, s->Ho, s->Wo, s->Hi, s->Wi, s->ksize, s->stride, ho, wo);
   HRSEG_CHECK_ARG(s->ldx >= s->Cin && s->ldy >= s->Cout, "%s: ld smaller than channel count", who);
-  HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 24) && (long)s->B * s->Ho * s->Wo < (1L << 24),
-                  "%s: more than 2^24 pixels per tensor is not supported (exact float index division)", who);
+  HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 31) && (long)s->B * s->Ho * s->Wo < (1L << 31),
+                  "%s: more than 2^31 pixels per tensor is not supported (32-bit pixel indices)", who);
   return 0;
 }
 
@@ -1351,8 +1354,9 @@ static void fill_wgrad_args(WgradArgs& a, const float* x, const float* dy, float
   a.x = x; a.dy = dy; a.dw = dw; a.ldx = s->ldx; a.lddy = s->ldy;
   a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.Cin = s->Cin; a.Ho = s->Ho; a.Wo = s->Wo; a.Cout = s->Cout;
   a.M = s->B * s->Ho * s->Wo; a.ks = s->ksize; a.stride = s->stride; a.T = s->ksize * s->ksize;
-  a.rcp_hw = 1.0f / (float)(s->Ho * s->Wo);
-  a.rcp_w = 1.0f / (float)s->Wo;
+  const bool big = (long)s->B * s->Ho * s->Wo >= (1L << 24);   // float-reciprocal division is exact below 2^24
+  a.rcp_hw = big ? 0.f : 1.0f / (float)(s->Ho * s->Wo);
+  a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
 }
 
 static bool mfma_shape(const hrseg_conv_shape_t* s) {
@@ -1551,8 +1555,9 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   a.x = x; a.dy = dy; a.dw = dw; a.ldx = s->ldx; a.lddy = s->ldy;
   a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.Cin = s->Cin; a.Ho = s->Ho; a.Wo = s->Wo; a.Cout = s->Cout;
   a.M = s->B * s->Ho * s->Wo; a.ks = s->ksize; a.stride = s->stride; a.T = T;
-  a.rcp_hw = 1.0f / (float)(s->Ho * s->Wo);
-  a.rcp_w = 1.0f / (float)s->Wo;
+  const bool big = (long)s->B * s->Ho * s->Wo >= (1L << 24);   // float-reciprocal division is exact below 2^24
+  a.rcp_hw = big ? 0.f : 1.0f / (float)(s->Ho * s->Wo);
+  a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
   const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
   const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
 #define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { if (int e = launch_wgrad<TN_, TK_>(a, st)) return e; }

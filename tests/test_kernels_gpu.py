@@ -97,6 +97,28 @@ def test_wgrad_row_variant(ops, case):
     assert rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 5e-5
 
 
+def test_conv_beyond_2p24_pixels(ops):
+    """tensors of 2^24 pixels or more take the integer-division index path (the float-reciprocal division is
+    exact only below 2^24): forward, data gradient and weight gradient of a 3x3 conv on a 4100x4100 image"""
+    H = W = 4100                                  # 16.81 M pixels > 2^24
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 16, H, W, generator=g)
+    w = (torch.randn(16, 16, 3, 3, generator=g) / 12).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, padding=1)
+    dy = torch.randn(1, 16, H, W, generator=g)
+    y_ref.backward(dy)
+    xd, wd = nhwc(x), store(w.detach())
+    y = ops.conv_fwd(xd, wd, None, 3, 1)
+    assert rel(nchw(y), y_ref) < 2e-5
+    dyd = nhwc(dy)
+    dw = torch.zeros_like(wd)
+    ops.conv_wgrad(xd, dyd, dw, 3, 1)
+    assert rel(dw.view(16, 3, 3, 16).permute(0, 3, 1, 2).cpu(), w.grad) < 2e-4      # 16.8 M-term fp32 sums
+    dx = ops.conv_dgrad(dyd, ops.weight_transpose(wd, 16, 9, 16), xd.shape, 3, 1)
+    assert rel(nchw(dx), xr.grad) < 2e-5
+
+
 def test_conv_into_channel_slice(ops):
     """output written into a channel slice of a wider NHWC buffer (concat without copy)"""
     g = torch.Generator().manual_seed(3)
