@@ -300,7 +300,7 @@ def test_batched_and_dedup_passes_equal_sequential_passes(name):
     assert worst < max(1e-1, 4 * worst_noise), (worst, worst_name, worst_noise)
     med = np.median([rel_err(ded["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     noise = np.median([rel_err(ref2["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
-    assert med < max(1e-2, 4 * noise), (med, noise)
+    assert med < max(2e-2, 4 * noise), (med, noise)
 
     # the default execution: the L passes batched into one launch per layer -- same checks
     assert abs(ref["loss"] - bat["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
@@ -316,7 +316,7 @@ def test_batched_and_dedup_passes_equal_sequential_passes(name):
     med_b = np.median([rel_err(bat["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     print(f"batched vs sequential: worst {worst_b:.3e} ({worst_b_name}), median {med_b:.3e}")
     assert worst_b < max(1e-1, 4 * worst_noise), (worst_b, worst_b_name, worst_noise)
-    assert med_b < max(1e-2, 4 * noise), (med_b, noise)
+    assert med_b < max(2e-2, 4 * noise), (med_b, noise)
 
 
 def test_full_size_step_properties():
