@@ -143,13 +143,15 @@ def test_missing_library_is_loud(tmp_path, monkeypatch):
         m(torch.zeros(1, 3, 32, 32), type=1)
 
 
-def test_graphed_train_step_tracks_eager():
-    """the hipGraph-replayed step (train.GraphedTrainStep) gives the eager step's losses"""
+@pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64"])
+def test_graphed_train_step_tracks_eager(name):
+    """the hipGraph-replayed step (train.GraphedTrainStep) gives the eager step's losses (UNet: sequential level
+    passes, HRNet: batched level passes)"""
     from hrseg_amd.Models import models as PM
     from hrseg_amd.Metrics import losses as PL
     from hrseg_amd import train as PT
-    kind, hier, tree_file, size, batch = CASES["unet_hier_tl_62"]
-    g = load_golden("unet_hier_tl_62")
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
     tree = load_tree(tree_file)
     num_classes = [int(v) for v in g["num_classes"]]
     weights = level_weights_for(tree_file, hier)
@@ -166,8 +168,12 @@ def test_graphed_train_step_tracks_eager():
     m, opt, fns = make()
     graphed = PT.GraphedTrainStep(m, opt, fns, args, tree, x, target, warmup=1)   # runs eager step 0
     got = [float(graphed(x, target)[0]) for _ in range(3)]
-    for a, b in zip(got, eager[1:]):
-        assert abs(a - b) < 2e-3 * abs(b), (got, eager)
+    # UNet: the trajectories stay within 2e-3.  HRNet at 64x64 (2x2-pixel lowest branch, BN over 8 samples) is
+    # chaotic: three EAGER runs from the same weights differ by 3e-4 / 2.5e-3 / 3e-3 at steps 2 / 3 / 4 (atomics
+    # reorder sums), so later replays are only required to track loosely; the first replay must match.
+    tols = [2e-3, 2e-3, 2e-3] if kind == "unet" else [5e-4, 1e-2, 3e-2]
+    for a, b, tol in zip(got, eager[1:], tols):
+        assert abs(a - b) < tol * abs(b), (got, eager)
     sd = opt.state_dict()                       # torch.optim.AdamW's layout; replays advance the device step counter
     assert all(float(st["step"]) == 4.0 for st in sd["state"].values()) and len(sd["state"]) == len(list(m.parameters()))
 
