@@ -198,7 +198,11 @@ def main():
     tree, model, ns, loss_fns, opt = build(args, device)
     sync = None
     if world > 1 or os.environ.get("HRSEG_FORCE_SYNC", "0") == "1":
-        sync = GradSync(model)
+        if os.environ.get("HRSEG_COMM", "torch") == "rccl":       # the library's own RCCL wrappers (hrseg_comm_*)
+            from hrseg_amd.parallel import RcclComm
+            sync = GradSync(model, backend="rccl", comm=RcclComm(rank, world, device))
+        else:                                                     # default: torch.distributed, backend nccl = RCCL
+            sync = GradSync(model)
         opt.grad_scale = 1.0 / world
     hier = not args.flat
     x, t = synth.synthetic_batch(tree, args.batch, args.size, seed=100 + rank, hierarchical=hier)

@@ -291,6 +291,18 @@ int hrseg_adamw_dev(float* p, const float* g, float* m, float* v, long n, const 
                     float* state, hrseg_stream_t stream);
 int hrseg_fill(float* p, float v, long n, hrseg_stream_t stream);
 
+/* ------------------------------------------------------------------ gradient exchange (data parallelism)
+ * Thin wrappers over RCCL for the one collective of the path: the in-place sum of a flat fp32 gradient
+ * bucket over the ranks (replaces nn.DataParallel's reduce-add, train.py:509-510).  librccl.so is opened
+ * on first use.  One communicator per process (= per GPU); the 128-byte id comes from ONE rank and is
+ * shipped to the others by the caller (file, TCP store, ...).  All calls are stream-ordered, none
+ * synchronises the host. */
+int hrseg_comm_unique_id(void* id128);
+int hrseg_comm_init(void** comm, int rank, int world, const void* id128);   /* collective over the ranks */
+int hrseg_comm_allreduce_async(void* comm, float* buf, long count, hrseg_stream_t stream);
+int hrseg_comm_wait(hrseg_stream_t comm_stream, hrseg_stream_t consumer);   /* consumer waits for comm_stream */
+int hrseg_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------ target encoding (input side of the path)
  * SegDataset.separate_masks / traverse_tree / process_ignore_values (Data/dataset.py:41-124,
  * 227-265): label image [B,hw] of uint8 pixel values -> out [B,C,hw] fp32 (NCHW planes).

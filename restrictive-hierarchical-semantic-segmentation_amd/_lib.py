@@ -99,6 +99,14 @@ PROTOTYPES = {
     "hrseg_fill": [_p, _f, _l, _p],
     "hrseg_encode_targets": [_p, _p, C.POINTER(C.c_int), _p, _i, _i, _l, _p],
 }
+# entry points without the trailing stream argument convention of `call`
+RAW_PROTOTYPES = {
+    "hrseg_comm_unique_id": [_p],
+    "hrseg_comm_init": [C.POINTER(_p), _i, _i, _p],
+    "hrseg_comm_allreduce_async": [_p, _p, _l, _p],
+    "hrseg_comm_wait": [_p, _p],
+    "hrseg_comm_destroy": [_p],
+}
 
 _lib.hrseg_last_error_string.restype = C.c_char_p
 _lib.hrseg_last_error_string.argtypes = []
@@ -147,6 +155,20 @@ for _name, _args in PROTOTYPES.items():
 
 
 ABI_VERSION = 4     # must equal hrseg_abi_version() of the built library (struct layouts above)
+
+
+raw = {}
+for _name, _args in RAW_PROTOTYPES.items():
+    f = getattr(_lib, _name)
+    f.argtypes = _args
+    f.restype = _i
+    raw[_name] = f
+
+
+def call_raw(name, *args):
+    rc = raw[name](*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
 
 
 def abi_version() -> int:

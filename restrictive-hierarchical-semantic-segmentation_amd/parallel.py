@@ -34,24 +34,70 @@ def bucket_offsets(flat, marks):
     return out
 
 
+class RcclComm:
+    """The library's own RCCL communicator (`hrseg_comm_*`, include/hrseg.h): one per process, the 128-byte
+    id travels from rank 0 through a TCP store at MASTER_ADDR:(MASTER_PORT+1).  `GradSync(backend="rccl")`
+    uses it instead of torch.distributed for the gradient all-reduce."""
+
+    def __init__(self, rank, world, device, addr=None, port=None):
+        import ctypes
+        import os
+        from . import _lib
+        self._lib, self.rank, self.world, self.device = _lib, rank, world, torch.device(device)
+        torch.cuda.set_device(self.device)
+        idbuf = ctypes.create_string_buffer(128)
+        if world > 1:
+            addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = port or int(os.environ.get("MASTER_PORT", "29500")) + 1
+            store = dist.TCPStore(addr, port, world, is_master=(rank == 0))
+            if rank == 0:
+                _lib.call_raw("hrseg_comm_unique_id", idbuf)
+                store.set("hrseg_rccl_id", idbuf.raw)
+            else:
+                idbuf.raw = store.get("hrseg_rccl_id")
+            self._store = store
+        else:
+            _lib.call_raw("hrseg_comm_unique_id", idbuf)
+        self._comm = ctypes.c_void_p()
+        _lib.call_raw("hrseg_comm_init", ctypes.byref(self._comm), rank, world, idbuf)
+
+    def all_reduce_(self, t, stream):
+        """in-place sum of a contiguous fp32 tensor over the ranks, stream-ordered on `stream`"""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        self._lib.call_raw("hrseg_comm_allreduce_async", self._comm, t.data_ptr(), t.numel(), stream.cuda_stream)
+
+    def wait(self, comm_stream, consumer):
+        self._lib.call_raw("hrseg_comm_wait", comm_stream.cuda_stream, consumer.cuda_stream)
+
+    def close(self):
+        if self._comm:
+            self._lib.call_raw("hrseg_comm_destroy", self._comm)
+            self._comm = None
+
+
 class GradSync:
     """Attach to a model: ``sync = GradSync(model, group); ...; loss.backward()`` leaves the
     summed gradient in model._flat.grad (the optimizer divides by world size)."""
 
     def __init__(self, model, group=None, marks=("layer1", "transition1", "transition2", "transition3",
-                                                 "shared_head", "down2", "down4", "up2", "up4"), min_bucket=1 << 20):
+                                                 "shared_head", "down2", "down4", "up2", "up4"), min_bucket=1 << 20,
+                 backend="torch", comm=None):
+        """backend "torch": torch.distributed (nccl = RCCL on ROCm, gloo on CPU); "rccl": the library's own
+        communicator `comm` (an RcclComm) through the C ABI."""
         self.model = model
         self.group = group
+        self.backend, self.comm = backend, comm
+        assert backend in ("torch", "rccl") and (backend == "torch" or comm is not None)
         self.marks = marks
         import os as _os
         if "HRSEG_SYNC_MIN_BUCKET" in _os.environ:        # elements; a huge value = one all-reduce at the end
             min_bucket = int(_os.environ["HRSEG_SYNC_MIN_BUCKET"])
         self.min_bucket = min_bucket
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = comm.world if backend == "rccl" else (dist.get_world_size(group) if dist.is_initialized() else 1)
         # HRSEG_FORCE_SYNC=1: issue the collectives even on a single rank (rehearses the RCCL + stream
         # choreography on a one-GPU box)
         import os
-        self.force = os.environ.get("HRSEG_FORCE_SYNC", "0") == "1" and dist.is_initialized()
+        self.force = os.environ.get("HRSEG_FORCE_SYNC", "0") == "1" and (dist.is_initialized() or backend == "rccl")
         self._comm_stream = None
         self._handles = []
         self._boundary = None
@@ -67,11 +113,25 @@ class GradSync:
         buffer (BN running statistics) are broadcast once."""
         m = self.model
         flat = m.flatten_parameters() if hasattr(m, "flatten_parameters") else getattr(m, "_flat", None)
+        bufs = list(m.buffers()) if hasattr(m, "buffers") else []
+        if self.backend == "rccl":
+            # broadcast = all-reduce with every other rank contributing zeros (the ABI has one collective)
+            cur = torch.cuda.current_stream()
+            packed = torch.cat([b.detach().reshape(-1).float() for b in bufs]) if bufs else None
+            for t in ([flat.data] if flat is not None else []) + ([packed] if packed is not None else []):
+                if self.comm.rank != src:
+                    t.zero_()
+                self.comm.all_reduce_(t, cur)
+            o = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.copy_(packed[o:o + b.numel()].view(b.shape).to(b.dtype))
+                    o += b.numel()
+            return
         if flat is not None and getattr(flat, "data", None) is not None:
             dist.broadcast(flat.data, src=src, group=self.group)
-        if hasattr(m, "buffers"):
-            for b in m.buffers():
-                dist.broadcast(b, src=src, group=self.group)
+        for b in bufs:
+            dist.broadcast(b, src=src, group=self.group)
 
     # the model calls this with a mark name while the last backward level runs, then with "end"
     def __call__(self, mark):
@@ -107,6 +167,9 @@ class GradSync:
             side = wgrad_stream(chunk.device)
             if side is not None:                 # the bucket's weight gradients come from the side stream
                 self._comm_stream.wait_stream(side)
+            if self.backend == "rccl":
+                self.comm.all_reduce_(chunk, self._comm_stream)
+                return
             with torch.cuda.stream(self._comm_stream):
                 self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -117,7 +180,10 @@ class GradSync:
             h.wait()
         self._handles = []
         if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if self.backend == "rccl":
+                self.comm.wait(self._comm_stream, torch.cuda.current_stream())
+            else:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
 
 
 def all_reduce_confusion(cms, group=None):

@@ -36,12 +36,13 @@ def test_header_symbols_exported_and_prototypes_match():
         if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_debug_set_conv_tune", "hrseg_debug_set_wgrad_tune",
                     "hrseg_debug_set_patch_mode", "hrseg_debug_set_wgrad_row", "hrseg_debug_set_group_wtm"):
             continue
-        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+        protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
+        assert name in protos, f"{name} has no ctypes prototype"
         want = [ctype_of(a) for a in args]
-        got = list(_lib.PROTOTYPES[name])
+        got = list(protos[name])
         got = [ctypes.c_void_p if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t for t in got]
         assert got == want, f"{name}: ctypes {got} != header {want}"
-    for name in _lib.PROTOTYPES:
+    for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
     assert _lib.abi_version() == 4
 

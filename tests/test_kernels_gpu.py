@@ -483,3 +483,40 @@ def test_grouped_conv_matches_single_launches(ops):
         if i in (1, 3):
             dx1 = dx1 + seed[i]
         assert rel(dxs[i], dx1) < 1e-5
+
+
+def test_rccl_comm_single_rank():
+    """the library's own RCCL wrappers (hrseg_comm_*): real communicator on one rank -- the in-place sum over
+    one rank leaves the bucket unchanged, is stream-ordered, and GradSync(backend="rccl") drives it per bucket"""
+    import types
+    from hrseg_amd.parallel import GradSync, RcclComm
+    comm = RcclComm(0, 1, "cuda:0")
+    try:
+        t = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+        want = t.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        comm.all_reduce_(t, s)
+        comm.wait(s, torch.cuda.current_stream())
+        assert torch.equal(t, want)
+        names = ["stem.0.weight", "layer1.0.w", "transition1.0.w", "stage2.0.w", "shared_head.0.weight"]
+        sizes = [4096, 1 << 20, 1 << 19, 1 << 21, 1 << 18]
+        slots, off = {}, 0
+        for n, sz in zip(names, sizes):
+            slots[n] = (off, sz)
+            off += sz
+        flat = types.SimpleNamespace(slots=slots, numel=off, grad=torch.randn(off, device="cuda"), data=torch.randn(off, device="cuda"))
+        model = types.SimpleNamespace(_flat=flat, _grad_hook=None)
+        import os
+        os.environ["HRSEG_FORCE_SYNC"] = "1"
+        try:
+            sync = GradSync(model, backend="rccl", comm=comm, min_bucket=1000)
+        finally:
+            del os.environ["HRSEG_FORCE_SYNC"]
+        before = flat.grad.clone()
+        for mark in ("shared_head", "transition1", "layer1", "end"):
+            sync(mark)
+        torch.cuda.synchronize()
+        assert torch.equal(flat.grad, before) and sync.launched[0][1] == off and sync.launched[-1][0] == 0
+    finally:
+        comm.close()
