@@ -520,3 +520,42 @@ def test_rccl_comm_single_rank():
         assert torch.equal(flat.grad, before) and sync.launched[0][1] == off and sync.launched[-1][0] == 0
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_conv_groups(ops, seed):
+    """seeded random groups of 2..8 independent convolutions (mixed channel counts and image sizes, 1x1 / 3x3,
+    stride 1 / 2, accumulate flags, batch 1..3) through the grouped entry points against autograd"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(2, 9))
+    k = int(rng.choice([1, 3]))
+    s = int(rng.choice([1, 2])) if k == 3 else 1
+    base = int(rng.choice([48, 64]))                 # a group shares its channel tiling (48- or 64-multiples)
+    g = torch.Generator().manual_seed(seed)
+    xs, ws, dys, refs = [], [], [], []
+    for _ in range(n):
+        cin, cout = base * int(rng.integers(1, 4)), base * int(rng.integers(1, 4))
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(3, 34)), int(rng.integers(3, 34))
+        x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
+        y = F.conv2d(x, w, stride=s, padding=(k - 1) // 2)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xs.append(x), ws.append(w), dys.append(dy), refs.append(y.detach())
+    xd, wd, dyd = [nhwc(x.detach()) for x in xs], [store(w.detach()) for w in ws], [nhwc(d) for d in dys]
+    couts = [w.shape[0] for w in ws]
+    ys = ops.conv_fwd_group(xd, wd, [None] * n, k, s, couts)
+    for y, r in zip(ys, refs):
+        assert rel(nchw(y), r) < 3e-5
+    dws = [torch.zeros_like(w) for w in wd]
+    ops.conv_wgrad_group(xd, dyd, dws, k, s)
+    for dw, w in zip(dws, ws):
+        co, ci = w.shape[0], w.shape[1]
+        assert rel(dw.view(co, k, k, ci).permute(0, 3, 1, 2).cpu(), w.grad) < 1e-4
+    wts = [ops.weight_transpose(w_, w.shape[0], k * k, w.shape[1]) for w_, w in zip(wd, ws)]
+    seeds = [torch.randn(x.shape, generator=g) if rng.random() < 0.5 else None for x in xd]
+    outs = [sd.clone().cuda() if sd is not None else None for sd in seeds]   # NHWC seeds the launch adds into
+    dxs = ops.conv_dgrad_group(dyd, wts, [x.shape for x in xd], k, s, outs, [o is not None for o in outs])
+    for dx, x, sd in zip(dxs, xs, seeds):
+        want = x.grad if sd is None else x.grad + sd.permute(0, 3, 1, 2)
+        assert rel(nchw(dx), want) < 3e-5
