@@ -559,3 +559,40 @@ def test_random_conv_groups(ops, seed):
     for dx, x, sd in zip(dxs, xs, seeds):
         want = x.grad if sd is None else x.grad + sd.permute(0, 3, 1, 2)
         assert rel(nchw(dx), want) < 3e-5
+
+
+@pytest.mark.parametrize("C,H,W,B,L,res", [(48, 13, 11, 2, 2, False), (96, 7, 9, 1, 4, True), (384, 3, 5, 2, 3, False)])
+def test_batchnorm_batched_passes(ops, C, H, W, B, L, res):
+    """the BN bookkeeping of the batched level passes: the tensor holds L identical copies of one pass's images
+    (stat_div), the running statistics take L updates (repeat), the backward normalises each copy with its own
+    gradient (nseg) -- against torch BatchNorm applied to ONE copy L times"""
+    g = torch.Generator().manual_seed(C + L)
+    y0 = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    r0 = torch.randn(B, C, H, W, generator=g) if res else None
+    dzs = [torch.randn(B, C, H, W, generator=g) for _ in range(L)]
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z_refs, dy_refs, dres_refs = [], [], []
+    for l in range(L):
+        yr = y0.clone().requires_grad_(True)
+        rr = r0.clone().requires_grad_(True) if res else None
+        z = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+        z = F.relu(z + rr if res else z)
+        z.backward(dzs[l])
+        z_refs.append(z.detach()), dy_refs.append(yr.grad), dres_refs.append(rr.grad if res else None)
+    y = nhwc(torch.cat([y0] * L))
+    it = dict(y=y, gamma=gamma.cuda(), beta=beta.cuda(), rm=torch.zeros(C, device="cuda"), rv=torch.ones(C, device="cuda"),
+              nbt=torch.zeros((), dtype=torch.int64, device="cuda"), momentum=0.1, eps=1e-5,
+              residual=nhwc(torch.cat([r0] * L)) if res else None, relu=True, repeat=L, stat_div=L)
+    (z, coef), = ops.bn_fwd_group([it], True)
+    assert rel(nchw(z), torch.cat(z_refs)) < 1e-5
+    assert rel(it["rm"], rm_ref) < 1e-5 and rel(it["rv"], rv_ref) < 1e-5 and int(it["nbt"]) == L
+    bw = dict(dz=nhwc(torch.cat(dzs)), z=z if res else None, relu=True, y=y, coef=coef, dgamma=torch.zeros(C, device="cuda"),
+              dbeta=torch.zeros(C, device="cuda"), dres=torch.empty_like(y) if res else None, dres_accumulate=False, nseg=L)
+    dy, = ops.bn_bwd_group([bw], False)
+    want = torch.cat(dy_refs)
+    assert float((nchw(dy) - want).abs().max()) < 2e-5 * max(float(want.abs().max()), 1.0)
+    assert rel(bw["dgamma"], gr.grad) < 2e-5 and rel(bw["dbeta"], br.grad) < 2e-5
+    if res:
+        assert rel(nchw(bw["dres"]), torch.cat(dres_refs)) < 1e-6
