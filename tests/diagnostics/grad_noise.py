@@ -1,7 +1,7 @@
 """How far are deep-path gradients from an fp64 evaluation, for the fp32 CPU oracle and for the
 GPU path?  (diagnostic; prints, asserts nothing)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree

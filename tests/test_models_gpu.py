@@ -80,7 +80,7 @@ def test_model_matches_reference_golden(name):
             got = named[key[6:]].grad.cpu().numpy()
             # head / FiLM gradients are a few ops from the loss; the first conv's sits behind every
             # BN/ReLU of the net, where fp32 evaluations differ from each other by ~1e-2 already
-            # (tools/grad_noise.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
+            # (tests/diagnostics/grad_noise.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
             tol = 5e-2 if key[6:].startswith(("stem", "inc0")) else 5e-3
             assert np.abs(got - g[key]).max() < tol * np.abs(g[key]).max() + 1e-6, key
     bufs = np.array([float(b.double().norm()) for _, b in model.named_buffers()])
@@ -302,7 +302,7 @@ def test_batched_and_dedup_passes_equal_sequential_passes(name):
     worst_noise, noise_name = worst_of(ref2)
     print(f"dedup vs faithful: worst {worst:.3e} ({worst_name}); faithful vs faithful: {worst_noise:.3e} ({noise_name})")
     # both are fp32 evaluations of the same sums in different order; early layers sit on the ~1e-2 fp32
-    # noise floor of this net (tools/grad_noise.py), so the bound is that floor, not rounding
+    # noise floor of this net (tests/diagnostics/grad_noise.py), so the bound is that floor, not rounding
     assert worst < max(1e-1, 4 * worst_noise), (worst, worst_name, worst_noise)
     med = np.median([rel_err(ded["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
     noise = np.median([rel_err(ref2["grads"][n], ga) for n, ga in ref["grads"].items() if np.abs(ga).max() > 0])
