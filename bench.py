@@ -125,6 +125,55 @@ def probe_dominant_kernel(device, batch, size):
             "traffic_source": traffic_src, "avg_launch_us": round(ms * 1e3, 2), "flop_per_launch": flops}
 
 
+def probe_secondary_kernels(device, batch, size):
+    """The next two kernel families by time, measured the same way (events on the launch stream, algorithmic work
+    over the measured duration): the grouped weight gradient of the branch convs (MFMA-bound) and the grouped
+    BatchNorm forward + backward of the four branches (HBM-bound; algorithmic bytes per element: statistics 4,
+    apply 8, backward reduce 8, backward apply 12 -- no residual, ReLU mask recomputed from y)."""
+    from hrseg_amd import ops
+    s4 = ((size + 1) // 2 + 1) // 2
+    sizes = [s4]
+    for _ in range(3):
+        sizes.append((sizes[-1] + 1) // 2)
+    chans = [48, 96, 192, 384]
+    xs = [torch.randn(batch, h, h, c, device=device) for c, h in zip(chans, sizes)]
+    dys = [torch.randn(batch, h, h, c, device=device) for c, h in zip(chans, sizes)]
+    dws = [torch.zeros(c, 9, c, device=device) for c in chans]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=20):
+        fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_w = timed(lambda: ops.conv_wgrad_group(xs, dys, dws, 3, 1))
+    fl = sum(2.0 * batch * h * h * c * c * 9 for c, h in zip(chans, sizes))
+    items = [dict(y=x, gamma=torch.ones(c, device=device), beta=torch.zeros(c, device=device),
+                  rm=torch.zeros(c, device=device), rv=torch.ones(c, device=device),
+                  nbt=torch.zeros((), dtype=torch.int64, device=device), momentum=0.1, eps=1e-5, residual=None, relu=True)
+             for x, c in zip(xs, chans)]
+    zc = ops.bn_fwd_group(items, True)
+    t_f = timed(lambda: ops.bn_fwd_group(items, True))
+    bw = [dict(dz=d.clone(), z=None, relu=True, y=x, coef=c_, dgamma=torch.zeros(c, device=device),
+               dbeta=torch.zeros(c, device=device), dres=None, dres_accumulate=False)
+          for d, x, (_, c_), c in zip(dys, xs, zc, chans)]
+    t_b = timed(lambda: ops.bn_bwd_group(bw, False))
+    elems = sum(x.numel() for x in xs)
+    gbs = elems * (12 + 20) / (t_f + t_b) / 1e9
+    return [
+        {"bound": "mfma", "kernel": "wgrad_group_kernel<3,3,64,1> (weight gradient of the four 3x3 branch convs, B=%d)" % batch,
+         "achieved": round(fl / t_w / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(fl / t_w / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(t_w * 1e6, 2)},
+        {"bound": "hbm", "kernel": "bn_{stats,finalize,apply}_group + bn_bwd_{reduce,finalize,apply}_group (four branches, B=%d)" % batch,
+         "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+         "algorithmic_bytes_per_element": 32, "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_b * 1e6, 2)},
+    ]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE, doubled as the
     gfx950 guide prescribes, + WRITE_SIZE; separate --pmc runs of one full train step, see profiles/README.md).
@@ -302,6 +351,8 @@ def main():
             # the level passes run batched: every conv launch sees batch * L images
             n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1
             line["roofline"] = probe_dominant_kernel(device, args.batch * n_pass, args.size)
+            if args.model == "hrnet":
+                line["roofline_other"] = probe_secondary_kernels(device, args.batch * n_pass, args.size)
             log("probe: %s" % json.dumps(line["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle train steps, batch 4, on %d cores) ..." % host_cores())

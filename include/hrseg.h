@@ -89,6 +89,7 @@ int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy,
 int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);
 /* experimental halo-patch kernel for 3x3 stride-1 convolutions: 0 = off (default), 1 = automatic */
 int hrseg_debug_set_patch_mode(int mode);
+int hrseg_debug_set_wgrad_group_plan(int mult, int min_blocks, int max_blocks);   /* grouped wgrad grid: blocks per problem = clamp(mult*tiles, min, max); 0 = default */
 int hrseg_debug_set_group_wtm(int wtm);   /* grouped conv launches: 0 automatic, 1 = 64-pixel, 2 = 128-pixel tiles */
 int hrseg_debug_set_wgrad_row(int on);   /* 1: a kernel ROW (3 taps) per weight-gradient block (default 0: one tap) */
 /* same for the weight-gradient kernel: pixels per LDS stage (64,128), LDS buffers, target grid size */

@@ -131,6 +131,16 @@ def set_wgrad_row(on=1):
 
 _lib.hrseg_debug_set_group_wtm.restype = _i
 _lib.hrseg_debug_set_group_wtm.argtypes = [_i]
+_lib.hrseg_debug_set_wgrad_group_plan.restype = _i
+_lib.hrseg_debug_set_wgrad_group_plan.argtypes = [_i, _i, _i]
+
+
+def set_wgrad_group_plan(mult=0, min_blocks=0, max_blocks=0):
+    _lib.hrseg_debug_set_wgrad_group_plan(mult, min_blocks, max_blocks)
+
+
+if "HRSEG_WGRAD_GROUP_PLAN" in os.environ:   # "mult,min,max" A/B switch for tuning runs
+    set_wgrad_group_plan(*[int(v) for v in os.environ["HRSEG_WGRAD_GROUP_PLAN"].split(",")])
 if "HRSEG_GROUP_WTM" in os.environ:          # A/B switch for tuning runs
     _lib.hrseg_debug_set_group_wtm(int(os.environ["HRSEG_GROUP_WTM"]))
 if "HRSEG_WGRAD_ROW" in os.environ:          # A/B switch for tuning runs

@@ -1209,11 +1209,20 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   return launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
 }
 
+static int g_wg_mult = 0, g_wg_min = 0, g_wg_max = 0;      // tuning overrides of the grouped weight-gradient grid
+extern "C" int hrseg_debug_set_wgrad_group_plan(int mult, int min_blocks, int max_blocks) {
+  g_wg_mult = mult; g_wg_min = min_blocks; g_wg_max = max_blocks;
+  return 0;
+}
 static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
   tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * (a.row ? 3 : a.T);
-  int target = 7 * tiles;
-  if (target < 512) target = 512;
-  if (target > 4096) target = 4096;
+  // measured (tools/wgrad_group_plan.py, groups of 2-4 branch convs at 4 and 8 images): 2 pixel ranges per tile
+  // set, at least 768 and at most 2048 blocks per problem -- 7 ranges per tile set left the 384-channel
+  // problem with 4032 blocks of 8 stages whose cross-wave reduction and atomics cost as much as their MFMAs
+  int target = (g_wg_mult ? g_wg_mult : 2) * tiles;
+  const int tmin = g_wg_min ? g_wg_min : 768, tmax = g_wg_max ? g_wg_max : 2048;
+  if (target < tmin) target = tmin;
+  if (target > tmax) target = tmax;
   int ksplit = target / tiles;
   if (ksplit < 1) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), pix) * pix;

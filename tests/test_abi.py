@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_prototypes_match():
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
         if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_debug_set_conv_tune", "hrseg_debug_set_wgrad_tune",
-                    "hrseg_debug_set_patch_mode", "hrseg_debug_set_wgrad_row", "hrseg_debug_set_group_wtm"):
+                    "hrseg_debug_set_patch_mode", "hrseg_debug_set_wgrad_row", "hrseg_debug_set_group_wtm", "hrseg_debug_set_wgrad_group_plan"):
             continue
         protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
         assert name in protos, f"{name} has no ctypes prototype"
