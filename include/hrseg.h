@@ -131,7 +131,7 @@ int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int 
                        float* dy, int lddy, float* dres, int lddres, int dres_accumulate,
                        long npix, int C, int eval_mode, hrseg_stream_t stream);
 
-/* Grouped forms: n (1..4) independent BatchNorm problems in three launches (statistics, finalize,
+/* Grouped forms: n (1..8) independent BatchNorm problems in three launches (statistics, finalize,
  * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward. */
 typedef struct {
   const float* y; int ldy; long npix; int C;       /* conv output [npix][C]                      */

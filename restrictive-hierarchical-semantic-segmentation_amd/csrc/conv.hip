@@ -11,7 +11,10 @@
 //    chunks.  A = weights (M = channels), B = pixels (N), so a lane ends up
 //    with 4 consecutive channels of one pixel -> one 16-byte NHWC store.
 //    dgrad is the same kernel on dy with the transposed weights and a tap
-//    table; stride-2 dgrad runs as 4 output-parity classes with 1/2/2/4 taps.
+//    table; stride-2 dgrad runs as 4 output-parity classes with 1/2/2/4 taps
+//    (one grouped launch).  Up to 8 independent problems (the parallel HRNet
+//    branches, the fuse paths of a module) share one launch (igemm_group).
+//    Operands are staged with BUFFER loads (see make_rsrc).
 //  * wgrad: dW[co][t][ci] = sum_pix dy[pix][co] * x[pix_t][ci]; each block owns
 //    one (tap, cout tile, cin tile) and a pixel range, its 4 waves split the
 //    pixels, reduce through LDS and add into dW with fp32 atomics (dW holds
