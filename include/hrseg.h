@@ -73,9 +73,11 @@ int hrseg_conv_wgrad(const float* x, const float* dy, float* dw,
  * transposed weight of a slot is written at the same offset of flat_t. */
 int hrseg_weight_transpose_all(const float* flat, float* flat_t, const int* table, int nentries,
                                hrseg_stream_t stream);
-/* Grouped forms: n independent convolutions (the parallel HRNet branches, models.py:524-525) in
- * ONE launch when they can share a kernel instance (channel counts all multiples of 48 or all of
- * 64, stride 1 for dgrad), else n separate launches.  Pointer arrays are HOST arrays. */
+/* Grouped forms: n independent convolutions (the parallel HRNet branches, models.py:524-525; the
+ * fuse paths of a module, :483-511) in ONE launch when n <= 8 and they can share a kernel instance
+ * (channel counts all multiples of 48 or all of 64), else n separate launches; a stride-2 data
+ * gradient is one launch per problem (its four parity classes grouped).  Problems of one data-gradient
+ * call must write distinct dx buffers.  Pointer arrays are HOST arrays. */
 int hrseg_conv_fwd_group(int n, const float* const* x, const float* const* w,
                          const float* const* bias, float* const* y,
                          const hrseg_conv_shape_t* shapes, hrseg_stream_t stream);
