@@ -3,10 +3,14 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model hrnet|unet] [--batch B] [--size S]
 
-One "step" = the reference's train-loop body on one synthetic batch (forward of the L level
-passes, prediction prep + metrics, CE+Dice+consistency loss, backward, gradient all-reduce,
-AdamW), inputs resident in HBM.  N>1 is launched by torch.distributed.run (one rank per GPU,
-RCCL); every rank works on its own 4-image shard (weak scaling) and rank 0 prints ONE JSON line.
+One "step" = the reference's train-loop batch body (train.py:179-248) on one synthetic batch: forward
+of the L level passes, prediction prep + metrics, CE+Dice+consistency loss, backward, gradient
+all-reduce, AdamW, the per-class metric vectors and the ONE device->host readback of loss + metrics;
+the batch is resident in HBM when the timed region starts (`value`).  The same body fed from pinned
+host memory (H2D copy inside the timed step) is measured next to it (`batch_body_from_host`).
+N>1: one rank per GPU over RCCL, every rank on its own 4-image shard (weak scaling), rank 0 prints ONE
+JSON line.  `python bench.py --gpus N` starts its own N ranks (torch.distributed.run as a child
+process, before this process touches the GPU); under torchrun (WORLD_SIZE set) it is a rank itself.
 
 Extra objects in that line:
   roofline     -- the dominant kernel (implicit-GEMM 3x3 conv 48->48 at 155x155, fp32 MFMA): algorithmic
@@ -28,6 +32,16 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+# model.conv_dtype -> what the convolution contractions execute
+CONV_ARITHMETIC = {
+    "f32": "fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 products)",
+    "bf16x3": "fp32 operands split exactly into 3 bf16 pieces, 6 products per tile on v_mfma_f32_16x16x32_bf16, "
+              "fp32 accumulate (fp32-grade: the dropped cross terms are below 2^-24 relative)",
+    "bf16x2": "fp32 operands split into 2 bf16 pieces, 3 products per tile on v_mfma_f32_16x16x32_bf16, fp32 "
+              "accumulate (2^-16 relative operand error)",
+    "bf16": "operands rounded to bf16, one product on v_mfma_f32_16x16x32_bf16, fp32 accumulate"}
+CONV_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1}
 TRAIN_GFLOP_PER_IMAGE = {          # BASELINE.md section 2 (conv+linear MACs x2, fwd+dgrad+wgrad = 3x fwd), 620x620
     ("hrnet", True): 1662.0, ("hrnet", False): 831.0, ("unet", True): 2168.0, ("unet", False): 1084.0}
 
@@ -49,6 +63,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--host-time", action="store_true", help="also log the host-side issue time of one step")
+    ap.add_argument("--no-bf16-line", action="store_true",
+                    help="skip the extra measurement of the opt-in bf16-input convolutions (N=1)")
     ap.add_argument("--no-dedup-line", action="store_true",
                     help="skip the extra measurement of the opt-in de-duplicated level passes (N=1, hierarchical)")
     return ap.parse_args()
@@ -84,7 +100,7 @@ def build(args, device):
     return tree, model, ns, loss_fns, opt
 
 
-def probe_dominant_kernel(device, batch, size):
+def probe_dominant_kernel(device, batch, size, conv_dtype="f32"):
     """The kernel with the largest share of the step is igemm_group_kernel: the 3x3 convs of the
     parallel HRNet branches (48/96/192/384 channels at size/4, /8, /16, /32), one grouped launch per
     BasicBlock conv.  One backbone pass issues 8 two-branch, 32 three-branch and 24 four-branch
@@ -125,7 +141,7 @@ def probe_dominant_kernel(device, batch, size):
             "traffic_source": traffic_src, "avg_launch_us": round(ms * 1e3, 2), "flop_per_launch": flops}
 
 
-def probe_secondary_kernels(device, batch, size):
+def probe_secondary_kernels(device, batch, size, conv_dtype="f32"):
     """The next two kernel families by time, measured the same way (events on the launch stream, algorithmic work
     over the measured duration): the grouped weight gradient of the branch convs (MFMA-bound) and the grouped
     BatchNorm forward + backward of the four branches (HBM-bound; algorithmic bytes per element: statistics 4,
@@ -229,19 +245,62 @@ def cpu_baseline(args, tree):
         OT.train_step(m, opt, xt, tt, nc if hier else [sum(nc)], w, hierarchical=hier, is_unet=(args.model == "unet"))
         steps += 1
     dt = time.time() - t0
-    return {"value": round(bs * steps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d full train step(s), batch %d, %dx%d, %s %s, torch-CPU oracle on %d threads (%.1f s)" % (
-                steps, bs, args.size, args.size, "hierarchical" if hier else "flat", args.model, cores, dt)}
+    out = {"value": round(bs * steps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": "%d full train step(s), batch %d, %dx%d, %s %s, torch-CPU oracle on %d threads (%.1f s)" % (
+               steps, bs, args.size, args.size, "hierarchical" if hier else "flat", args.model, cores, dt)}
+    # BASELINE.json configs[0], exactly as written: UNet donor, non-hierarchical, batch 2, 128x128, 7 classes
+    m0 = OM.UNet(size=128, n_channels=3, hierarchy=tree, model_type=0)
+    opt0 = torch.optim.AdamW(m0.parameters(), lr=1e-4)
+    x0, t0_ = synth.synthetic_batch(tree, 2, 128, seed=2, hierarchical=False)
+    x0, t0_ = torch.from_numpy(x0), torch.from_numpy(t0_)
+    nleaf = [sum(get_classes(tree, full=False))]
+    OT.train_step(m0, opt0, x0, t0_, nleaf, synth.README_LEVEL_WEIGHTS_FLAT, hierarchical=False, is_unet=True)   # warm-up
+    tc, n0 = time.time(), 0
+    while n0 < 20 and (n0 < 3 or time.time() - tc < 4.0):
+        OT.train_step(m0, opt0, x0, t0_, nleaf, synth.README_LEVEL_WEIGHTS_FLAT, hierarchical=False, is_unet=True)
+        n0 += 1
+    d0 = time.time() - tc
+    out["configs0"] = {"value": round(2 * n0 / d0, 3), "unit": "images/s", "ms_per_step": round(1e3 * d0 / n0, 1),
+                       "sample": "%d train steps, UNet flat (model_type 0), batch 2, 128x128, 7 classes, torch-CPU oracle "
+                                 "on %d threads" % (n0, cores)}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks as a CHILD
+    torch.distributed.run job (this process has not touched the GPU and never will), relay rank 0's JSON
+    line and the job's exit code.  Reference analogue: train.py:509-510 (nn.DataParallel over all GPUs)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode != 0 or lines else 1
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    import torch.distributed as dist
     from hrseg_amd.parallel import GradSync, init_distributed
     from hrseg_amd import train as T
+    from hrseg_amd.Metrics.performance_metrics import METRIC_NAMES
     from hrseg_amd.utils import synth
     rank, local, world = init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     tree, model, ns, loss_fns, opt = build(args, device)
@@ -254,8 +313,9 @@ def main():
             sync = GradSync(model)
         opt.grad_scale = 1.0 / world
     hier = not args.flat
-    x, t = synth.synthetic_batch(tree, args.batch, args.size, seed=100 + rank, hierarchical=hier)
-    x, t = torch.from_numpy(x).to(device), torch.from_numpy(t).to(device)
+    x_np, t_np = synth.synthetic_batch(tree, args.batch, args.size, seed=100 + rank, hierarchical=hier)
+    x_host, t_host = torch.from_numpy(x_np).pin_memory(), torch.from_numpy(t_np).pin_memory()
+    x, t = x_host.to(device), t_host.to(device)
     model.train()
     level_loss = []
 
@@ -263,7 +323,23 @@ def main():
     if world == 1 and args.graph:
         graphed = T.GraphedTrainStep(model, opt, loss_fns, ns, tree, x, t, warmup=1)
 
+    def body(xd, td):
+        """the batch body of train_epoch (train.py:179-248): step, metric vectors, ONE device->host copy"""
+        if graphed is not None:
+            loss, cms = graphed(xd, td)
+        else:
+            loss, cms = T.train_step(model, opt, xd, td, loss_fns, ns, tree, level_loss)
+        vec = T._metric_vectors(cms)
+        host = torch.cat([loss.reshape(1)] + [vec[k] for k in METRIC_NAMES]).tolist()
+        return host[0]
+
     def step():
+        return body(x, t)
+
+    def step_from_host():
+        return body(x_host.to(device, non_blocking=True), t_host.to(device, non_blocking=True))
+
+    def step_async():
         if graphed is not None:
             return graphed(x, t)
         return T.train_step(model, opt, x, t, loss_fns, ns, tree, level_loss)
@@ -272,60 +348,75 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        return dt, out
+
     log("model on %s, %d params; warmup %d, steps %d" % (device, sum(p.numel() for p in model.parameters()),
                                                           args.warmup, args.steps))
     for i in range(args.warmup):
         tw = time.perf_counter()
-        loss, _ = step()
+        loss = step()
         torch.cuda.synchronize()
         log("warmup step %d: %.3f s, loss %.5f, peak mem %.1f GB" % (i, time.perf_counter() - tw, float(loss),
                                                                     torch.cuda.max_memory_allocated() / 2**30))
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, cms = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
-    final_loss = float(loss)
+    dt, final_loss = timed(step, args.steps)
+    dt_host, _ = timed(step_from_host, args.steps)
+    dt_async, _ = timed(step_async, args.steps)
     if args.host_time:
         for _ in range(2):
             torch.cuda.synchronize()
             th = time.perf_counter()
-            step()
+            step_async()
             t_issue = time.perf_counter() - th
             torch.cuda.synchronize()
             log("host issue %.1f ms, step complete after %.1f ms" % (1e3 * t_issue, 1e3 * (time.perf_counter() - th)))
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
+        conv_dtype = getattr(model, "conv_dtype", "f32")
         line = {
             "metric": "train images/sec (620x620, hier-HRNet-W48)" if (args.model == "hrnet" and hier and args.size == 620) else
             "train images/sec (%dx%d, %s%s)" % (args.size, args.size, "hier-" if hier else "flat-", args.model),
             "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %s (%s), %dx%d, batch %d per GPU, full train step (fwd L passes, metrics, "
-                                   "CE+Dice+consistency, bwd, grad all-reduce, AdamW)" % (
+            "config": {"workload": "%s %s (%s), %dx%d, batch %d per GPU, train_epoch batch body (fwd L passes, prediction prep "
+                                   "+ metrics, CE+Dice+consistency, bwd, grad all-reduce, AdamW, metric vectors, one D2H "
+                                   "readback of loss+metrics)" % (
                                        "HRNet-W48" if args.model == "hrnet" else "UNet",
                                        "hierarchical" if hier else "flat", args.tree, args.size, args.size, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "launch": "hipGraph replay" if graphed is not None else "eager"},
+                       "launch": "hipGraph replay" if graphed is not None else "eager",
+                       "conv_arithmetic": CONV_ARITHMETIC.get(conv_dtype, conv_dtype),
+                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+                       "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
+            "batch_body_from_host": {"value": round(world * args.batch * args.steps / dt_host, 3), "unit": "images/s",
+                                     "ms_per_step": round(1e3 * dt_host / args.steps, 2),
+                                     "note": "same body with the batch copied from pinned host memory inside the timed "
+                                             "step (train.py:181); never the headline value"},
+            "ms_per_step_no_readback": round(1e3 * dt_async / args.steps, 2),
         }
         if gf is not None and args.size == 620:
             tf = ips * gf / 1e3
             line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),
                                           "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4)}
-        log("timed: %.3f s for %d steps" % (dt, args.steps))
+        log("timed: %.3f s for %d steps (resident), %.3f s (from host), %.3f s (no readback)" % (dt, args.steps, dt_host, dt_async))
         line["config"]["level_passes"] = ("sequential" if getattr(model, "sequential_passes", False) else
                                           "batched (one launch per layer for all L passes)") if hier else "n/a"
         if world == 1 and hier and graphed is None and not args.no_dedup_line:
@@ -334,12 +425,7 @@ def main():
             model.dedup_passes = True
             for _ in range(2):
                 step()
-            torch.cuda.synchronize()
-            td = time.perf_counter()
-            for _ in range(args.steps):
-                loss_d, _ = step()
-            torch.cuda.synchronize()
-            td = time.perf_counter() - td
+            td, _ = timed(step, args.steps)
             model.dedup_passes = False
             line["opt_in_dedup_passes"] = {
                 "value": round(args.batch * args.steps / td, 3), "unit": "images/s",
@@ -347,20 +433,33 @@ def main():
                 "note": "explicit opt-in (model.dedup_passes / HRSEG_DEDUP_PASSES=1); the default and headline value "
                         "execute all L passes"}
             log("opt-in dedup passes: %.1f ms/step" % (1e3 * td / args.steps))
+        if world == 1 and graphed is None and not args.no_bf16_line and hasattr(model, "conv_dtype"):
+            # NOT the headline: bf16-input / fp32-accumulate convolutions (BASELINE configs[4] arithmetic), opt-in
+            prev = model.conv_dtype
+            model.conv_dtype = "bf16"
+            for _ in range(2):
+                step()
+            tb, _ = timed(step, args.steps)
+            model.conv_dtype = prev
+            line["opt_in_bf16_convs"] = {
+                "value": round(args.batch * args.steps / tb, 3), "unit": "images/s", "ms_per_step": round(1e3 * tb / args.steps, 2),
+                "dtype": "bf16 inputs, fp32 accumulate (convolutions only; BN, loss, optimizer fp32)",
+                "note": "explicit opt-in (model.conv_dtype='bf16'): results differ from the fp32 reference beyond 1e-3"}
+            log("opt-in bf16 convs: %.1f ms/step" % (1e3 * tb / args.steps))
         if not args.no_probe:
             # the level passes run batched: every conv launch sees batch * L images
             n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1
-            line["roofline"] = probe_dominant_kernel(device, args.batch * n_pass, args.size)
+            line["roofline"] = probe_dominant_kernel(device, args.batch * n_pass, args.size, conv_dtype)
             if args.model == "hrnet":
-                line["roofline_other"] = probe_secondary_kernels(device, args.batch * n_pass, args.size)
+                line["roofline_other"] = probe_secondary_kernels(device, args.batch * n_pass, args.size, conv_dtype)
             log("probe: %s" % json.dumps(line["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle train steps, batch 4, on %d cores) ..." % host_cores())
             line["cpu_baseline"] = cpu_baseline(args, tree)
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -86,16 +86,10 @@ int hrseg_conv_dgrad_group(int n, const float* const* dy, const float* const* wt
                            hrseg_stream_t stream);
 int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy, float* const* dw,
                            const hrseg_conv_shape_t* shapes, hrseg_stream_t stream);
-/* tuning/debug: override the implicit-GEMM tile plan (0 = automatic) -- pixel tiles per wave
- * (1,2,4), 16-channel K chunks per stage (1-3), LDS buffers (1,2), split-K factor */
-int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit);
-/* experimental halo-patch kernel for 3x3 stride-1 convolutions: 0 = off (default), 1 = automatic */
-int hrseg_debug_set_patch_mode(int mode);
-int hrseg_debug_set_wgrad_group_plan(int mult, int min_blocks, int max_blocks);   /* grouped wgrad grid: blocks per problem = clamp(mult*tiles, min, max); 0 = default */
-int hrseg_debug_set_group_wtm(int wtm);   /* grouped conv launches: 0 automatic, 1 = 64-pixel, 2 = 128-pixel tiles */
-int hrseg_debug_set_wgrad_row(int on);   /* 1: a kernel ROW (3 taps) per weight-gradient block (default 0: one tap) */
-/* same for the weight-gradient kernel: pixels per LDS stage (64,128), LDS buffers, target grid size */
-int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks);
+/* tile-plan overrides for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
+ * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
+ * wgrad_group_min, wgrad_group_max (csrc/conv.hip, hrseg_tune).  Unknown key: HRSEG_ERR_INVALID_ARG. */
+int hrseg_tune(const char* key, int value);
 /* wt[ci][t][co] = w[co][t][ci] */
 int hrseg_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin,
                            hrseg_stream_t stream);
@@ -144,11 +138,6 @@ typedef struct {
   float* z; int ldz;
   float* coef;                                       /* out: [4][C] mean, rstd, scale, shift       */
   double* partial; int nchunks;                      /* scratch nchunks*2*C doubles (training)     */
-  double* acc; int* counter;                         /* optional one-launch statistics: acc = 2*C
-                                                        doubles, counter = one int, both ZERO before
-                                                        the first use; the kernels leave them zero, so
-                                                        one workspace serves every later call on a
-                                                        stream.  NULL: partial + a finalize launch    */
   int stat_div;                                      /* training: the tensor holds stat_div identical
                                                         copies of one pass's images (batched level
                                                         passes); the unbiased-variance factor uses
@@ -168,8 +157,6 @@ typedef struct {
   float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
   long npix; int C;
   double* partial; int nchunks;                      /* scratch (nchunks+max(nseg,1))*2*C doubles   */
-  double* acc; int* counter;                         /* as in hrseg_bn_fwd_t, acc = max(nseg,1)*2*C
-                                                        doubles; NULL: partial + a finalize launch    */
   int nseg;                                          /* > 1: npix is nseg equal segments (the batched
                                                         level passes), each normalised on its own: the
                                                         batch means of the backward are per segment;

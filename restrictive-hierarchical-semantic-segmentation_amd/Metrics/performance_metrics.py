@@ -44,20 +44,40 @@ def metrics_from_confusion(cm: torch.Tensor, child_classes: bool):
             "precision": _safe_div(tp, tp + fp).float(), "recall": rec}
 
 
-_cache = {"key": None, "cm": None}
+# The five metric objects are called back to back on the same (probs, targets) pair (reference
+# train.py:47-51).  Inside `shared_confusion()` -- entered by train.get_metrics around exactly those five
+# calls -- the counts of a pair are computed once and shared; the scope holds the tensors themselves, so a
+# key can never outlive its tensors (device addresses are recycled by the caching allocator from one step to
+# the next and the kernels write through raw pointers, so neither data_ptr nor _version identifies a batch).
+# Outside a scope every call counts afresh.
+_scope = None
+
+
+class shared_confusion:
+    """with shared_confusion(): ...  -- metric calls on the same tensor objects share one counting pass"""
+
+    def __enter__(self):
+        global _scope
+        self._outer, _scope = _scope, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _scope
+        _scope = self._outer
+        return False
 
 
 def confusion_for(probs, targets, child_classes):
-    """Confusion counts of (argmax targets, argmax probs); the five metric objects are
-    called back to back on the same tensors, so the last result is reused."""
-    key = (probs.data_ptr(), probs._version, targets.data_ptr(), targets._version, tuple(probs.shape),
-           bool(child_classes))
-    if _cache["key"] != key:
-        p = probs.contiguous().float()
-        t = targets.contiguous().float()
-        _, cm = ops.predict_metrics(p, t, child=bool(child_classes), mask_pred=False, want_onehot=False)
-        _cache["key"], _cache["cm"] = key, cm
-    return _cache["cm"]
+    """Confusion counts [K,K] of (argmax targets, argmax probs), K = C + child"""
+    key = (id(probs), id(targets), bool(child_classes))
+    if _scope is not None and key in _scope:
+        return _scope[key][0]
+    p = probs.contiguous().float()
+    t = targets.contiguous().float()
+    _, cm = ops.predict_metrics(p, t, child=bool(child_classes), mask_pred=False, want_onehot=False)
+    if _scope is not None:
+        _scope[key] = (cm, probs, targets)          # the references keep the ids unique within the scope
+    return cm
 
 
 class _Metric(torch.nn.Module):

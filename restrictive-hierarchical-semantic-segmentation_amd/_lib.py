@@ -39,15 +39,14 @@ class BnFwd(C.Structure):
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
                 ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
-                ("acc", _p), ("counter", _p), ("stat_div", _i), ("stat_updates", _i)]
+                ("stat_div", _i), ("stat_updates", _i)]
 
 
 class BnBwd(C.Structure):
     """hrseg_bn_bwd_t"""
     _fields_ = [("dz", _p), ("lddz", _i), ("z", _p), ("ldz", _i), ("relu", _i), ("y", _p), ("ldy", _i), ("coef", _p),
                 ("dgamma", _p), ("dbeta", _p), ("dy", _p), ("lddy", _i), ("dres", _p), ("lddres", _i),
-                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("acc", _p), ("counter", _p),
-                ("nseg", _i)]
+                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("nseg", _i)]
 
 
 # name -> argtypes, exactly the prototypes of include/hrseg.h
@@ -113,47 +112,27 @@ _lib.hrseg_last_error_string.argtypes = []
 _lib.hrseg_abi_version.restype = _i
 _lib.hrseg_abi_version.argtypes = []
 
-_lib.hrseg_debug_set_conv_tune.restype = _i
-_lib.hrseg_debug_set_conv_tune.argtypes = [_i, _i, _i, _i]
+_lib.hrseg_tune.restype = _i
+_lib.hrseg_tune.argtypes = [C.c_char_p, _i]
 
 
-_lib.hrseg_debug_set_wgrad_tune.restype = _i
-_lib.hrseg_debug_set_wgrad_tune.argtypes = [_i, _i, _i]
-
-
-_lib.hrseg_debug_set_wgrad_row.restype = _i
-_lib.hrseg_debug_set_wgrad_row.argtypes = [_i]
-
-
-def set_wgrad_row(on=1):
-    _lib.hrseg_debug_set_wgrad_row(int(on))
-
-
-_lib.hrseg_debug_set_group_wtm.restype = _i
-_lib.hrseg_debug_set_group_wtm.argtypes = [_i]
-_lib.hrseg_debug_set_wgrad_group_plan.restype = _i
-_lib.hrseg_debug_set_wgrad_group_plan.argtypes = [_i, _i, _i]
-
-
-def set_wgrad_group_plan(mult=0, min_blocks=0, max_blocks=0):
-    _lib.hrseg_debug_set_wgrad_group_plan(mult, min_blocks, max_blocks)
-
-
-if "HRSEG_WGRAD_GROUP_PLAN" in os.environ:   # "mult,min,max" A/B switch for tuning runs
-    set_wgrad_group_plan(*[int(v) for v in os.environ["HRSEG_WGRAD_GROUP_PLAN"].split(",")])
-if "HRSEG_GROUP_WTM" in os.environ:          # A/B switch for tuning runs
-    _lib.hrseg_debug_set_group_wtm(int(os.environ["HRSEG_GROUP_WTM"]))
-if "HRSEG_WGRAD_ROW" in os.environ:          # A/B switch for tuning runs
-    set_wgrad_row(int(os.environ["HRSEG_WGRAD_ROW"]))
-
-
-def set_wgrad_tune(pix=0, db=0, target_blocks=0):
-    _lib.hrseg_debug_set_wgrad_tune(pix, db, target_blocks)
+def tune(**kv):
+    """tile-plan overrides of the library (hrseg_tune; 0 = automatic), e.g. tune(igemm_wtm=2, igemm_kc=1)"""
+    for k, v in kv.items():
+        if _lib.hrseg_tune(k.encode(), int(v)) != 0:
+            raise RuntimeError(f"hrseg_tune({k}) failed: {last_error()}")
 
 
 def set_conv_tune(wtm=0, kc=0, db=0, ksplit=0):
-    """tuning/debug override of the implicit-GEMM tile plan (0 = automatic)"""
-    _lib.hrseg_debug_set_conv_tune(wtm, kc, db, ksplit)
+    tune(igemm_wtm=wtm, igemm_kc=kc, igemm_db=db, igemm_ksplit=ksplit)
+
+
+def set_wgrad_tune(pix=0, db=0, target_blocks=0):
+    tune(wgrad_pix=pix, wgrad_db=db, wgrad_blocks=target_blocks)
+
+
+def set_wgrad_group_plan(mult=0, min_blocks=0, max_blocks=0):
+    tune(wgrad_group_mult=mult, wgrad_group_min=min_blocks, wgrad_group_max=max_blocks)
 
 
 _fn = {}
@@ -164,7 +143,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 4     # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 5     # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}
@@ -230,3 +209,7 @@ def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("hrseg_amd: no GPU visible; the product path runs on MI355X only "
                            "(the CPU oracle under oracle/ is test infrastructure, not a fallback)")
+
+
+if "HRSEG_TUNE" in os.environ:               # "key=value,key=value" A/B switch for tuning runs
+    tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["HRSEG_TUNE"].split(",") if kv})

@@ -586,9 +586,8 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 // n independent BatchNorm problems (the parallel HRNet branches, or just one) per launch: block
 // ranges [blk_end[g-1], blk_end[g]) belong to problem g.  Three launches forward (statistics,
 // finalize, apply) and three backward (reduce, finalize, apply) whatever n is.  (Folding the finalize
-// into the statistics kernel -- last block to finish reduces the partials -- was measured 2-3x SLOWER:
-// one block reading up to 600 KB of cold partials takes 30-60 us against 7 us for the C/16-block
-// finalize launch, and a device-scope fence per block costs L2 write-backs.)
+// into the statistics kernel was measured slower twice -- last block reducing cold partials: 2-3x; fp64
+// atomics into one accumulator: blocks finishing together serialise on 2*C addresses -- see DESIGN.md.)
 #define BN_MAXG 8
 struct BnGroupHdr { int n; int blk_end[BN_MAXG]; };
 __device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nblk) {
@@ -606,7 +605,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
                                            int ldz, int relu, const float* __restrict__ yy, int ldy,
                                            const float* __restrict__ coef, long npix, int C,
                                            double* __restrict__ partial, int chunk, int nchunks, bool bwd,
-                                           double* red, int nseg = 1, double* acc = nullptr) {
+                                           double* red, int nseg = 1) {
   // forward: sums of a0 and a0^2; backward: sums of g and g*xhat with g = a0 * (zmask > 0 if relu)
   // nseg > 1: the pixel range is nseg equal segments (the batched level passes); a chunk never
   // straddles two segments (nchunks is a multiple of nseg)
@@ -658,38 +657,9 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
       a += red[t * 8 + (c & 3)];
       b += red[t * 8 + 4 + (c & 3)];
     }
-    if (acc) {
-      // one-launch mode: the chunk sums go straight into the segment's [2][C] accumulator (device-scope
-      // fp64 atomics; the returned value is consumed so the atomic has been performed before the ticket)
-      const double o0 = __hip_atomic_fetch_add(&acc[((size_t)seg * 2 + 0) * C + c], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double o1 = __hip_atomic_fetch_add(&acc[((size_t)seg * 2 + 1) * C + c], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(o0), "v"(o1));
-    } else {
-      partial[((size_t)chunk * 2 + 0) * C + c] = a;
-      partial[((size_t)chunk * 2 + 1) * C + c] = b;
-    }
+    partial[((size_t)chunk * 2 + 0) * C + c] = a;
+    partial[((size_t)chunk * 2 + 1) * C + c] = b;
   }
-}
-
-// One-launch statistics: every block adds its chunk sums into a [nseg][2][C] fp64 accumulator with
-// device-scope atomics and takes a ticket; the block with the last ticket reads the totals (2C values --
-// not the nchunks x 2C partials a last-block reduction would have to pull from cold memory, which was
-// measured 3x slower than a finalize launch), does the finalize and leaves accumulator and ticket
-// counter zeroed for the next launch on the stream.  Only atomics carry the data, so no cache
-// write-back / invalidate fences are needed: a block's atomics have returned before its ticket, and the
-// last block reads the totals with atomics again.
-__device__ __forceinline__ bool arrive_last(int* counter, int nblk) {
-  __shared__ int s_last;
-  __syncthreads();                      // every thread's accumulator atomics have returned (values consumed)
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == nblk - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-__device__ __forceinline__ double acc_take(double* p) {      // read the total and leave zero behind
-  return __hip_atomic_exchange(p, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void bn_finalize_channel(const hrseg_bn_fwd_t& p, int c, double s, double ss) {
@@ -727,17 +697,7 @@ __global__ __launch_bounds__(256) void bn_stats_group_kernel(BnFwdG g) {
   __shared__ double red[256 * 8];
   int local, nblk;
   const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
-  stats_body(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1,
-             p.acc);
-  if (!p.acc || !arrive_last(p.counter, nblk)) return;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(p.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p.num_batches_tracked) *(long long*)p.num_batches_tracked += (p.stat_updates > 1 ? p.stat_updates : 1);
-  }
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    const double s = acc_take(&p.acc[c]), ss = acc_take(&p.acc[p.C + c]);
-    bn_finalize_channel(p, c, s, ss);
-  }
+  stats_body(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
@@ -790,24 +750,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
-             nseg, p.acc);
-  if (!p.acc || !arrive_last(p.counter, nblk)) return;
-  if (threadIdx.x == 0) __hip_atomic_store(p.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int C = p.C;
-  double* totals = p.partial + (size_t)p.nchunks * 2 * C;      // [nseg][2][C], read by the apply kernel
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double s_all = 0.0, sx_all = 0.0;
-    for (int seg = 0; seg < nseg; ++seg) {
-      const double sv = acc_take(&p.acc[((size_t)seg * 2 + 0) * C + c]);
-      const double sx = acc_take(&p.acc[((size_t)seg * 2 + 1) * C + c]);
-      totals[(size_t)seg * 2 * C + c] = sv;
-      totals[(size_t)seg * 2 * C + C + c] = sx;
-      s_all += sv;
-      sx_all += sx;
-    }
-    if (p.dgamma) p.dgamma[c] += (float)sx_all;
-    if (p.dbeta) p.dbeta[c] += (float)s_all;
-  }
+             nseg);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
@@ -1127,17 +1070,12 @@ extern "C" int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* probs, int traini
   int end = 0;
   if (training) {
     for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-    bool fused = true;                 // every problem brings an accumulator: statistics + finalize in one launch
-    for (int i = 0; i < n; ++i) fused = fused && probs[i].acc && probs[i].counter;
-    if (!fused) for (int i = 0; i < n; ++i) g.p[i].acc = nullptr;
     hipLaunchKernelGGL(bn_stats_group_kernel, dim3(end), dim3(256), 0, st, g);
     HRSEG_LAUNCH_CHECK("bn_stats_group");
-    if (!fused) {
-      end = 0;
-      for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
-      hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
-      HRSEG_LAUNCH_CHECK("bn_finalize_group");
-    }
+    end = 0;
+    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_finalize_group");
   } else {
     for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 64); g.h.blk_end[i] = end; }
     hipLaunchKernelGGL(bn_eval_coef_group_kernel, dim3(end), dim3(64), 0, st, g);
@@ -1166,17 +1104,12 @@ extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_m
   }
   int end = 0;
   for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-  bool fused = true;
-  for (int i = 0; i < n; ++i) fused = fused && probs[i].acc && probs[i].counter;
-  if (!fused) for (int i = 0; i < n; ++i) g.p[i].acc = nullptr;
   hipLaunchKernelGGL(bn_bwd_reduce_group_kernel, dim3(end), dim3(256), 0, st, g);
   HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
-  if (!fused) {
-    end = 0;
-    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
-    hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
-    HRSEG_LAUNCH_CHECK("bn_bwd_finalize_group");
-  }
+  end = 0;
+  for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+  hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+  HRSEG_LAUNCH_CHECK("bn_bwd_finalize_group");
   end = 0;
   for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
   hipLaunchKernelGGL(bn_bwd_apply_group_kernel, dim3(end), dim3(256), 0, st, g, eval_mode);

@@ -21,6 +21,7 @@
 //    the running gradient of the step, so the add IS the accumulation).
 //  * Cin <= 4 (the image layer): direct VALU kernels.
 #include "common.h"
+#include <string.h>
 
 // ---------------------------------------------------------------------------
 struct IgemmArgs {
@@ -316,12 +317,8 @@ static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
   else hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, false>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
 }
 
-// debug/tuning override (0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
+// tuning overrides (hrseg_tune, 0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
 static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
-extern "C" int hrseg_debug_set_conv_tune(int wtm, int kc, int db, int ksplit) {
-  g_tune_wtm = wtm; g_tune_kc = kc; g_tune_db = db; g_tune_ksplit = ksplit;
-  return 0;
-}
 
 // zero fill as a KERNEL node (not hipMemsetAsync): keeps a captured hipGraph a pure kernel chain
 __global__ void zero_f32_kernel(float* __restrict__ p, size_t n) {
@@ -406,191 +403,10 @@ static int dispatch_igemm(const IgemmArgs& a_in, hipStream_t st) {
   return HRSEG_ERR_UNSUPPORTED;
 }
 
-// --------------------------------------------------------------------------- 3x3 stride-1: halo-patch kernel
-// The im2col kernel above pulls every input pixel through the vector-memory path nine times; an
-// in-kernel stamp profile (tools/ubench/igemm_lab.hip) shows its waves stalled at ISSUING global loads
-// for a third of each stage: the per-CU texture-address path, not HBM or MFMA, is the limit.  For 3x3
-// stride-1 convolutions (forward and data-gradient: 80 % of the HRNet FLOPs, all of UNet's) this
-// kernel stages a (TH+2) x 18 input patch per 16-channel chunk ONCE and lets the nine taps read it
-// from LDS with shifted row addresses: 2.6x fewer load instructions per MFMA.
-//   block = TH x 16 output pixels x 16*WTN channels, 4 waves x (TH/4) pixel rows each;
-//   LDS: patch [(TH+2)*18 rows][20 floats] (80-byte rows spread the banks), weights [9][BN][16] swizzled.
-struct PatchArgs {
-  const float* x; const float* w; const float* bias; float* y;
-  int ldx, ldy, B, H, W, K, N;   // input/output images are H x W (stride 1, pad 1)
-  int tiles_x, tiles_y;
-  int flip;                      // 1: data-gradient geometry (tap t reads the patch at tap 8-t)
-  int accumulate;
-};
-
-template <int TH, int WTN>
-__global__ __launch_bounds__(256) void igemm_patch_kernel(PatchArgs p) {
-  constexpr int BN = 16 * WTN, PW = 18, PROWS = (TH + 2) * PW, PSTR = 20;
-  constexpr int P_F4 = PROWS * 4, W_F4 = BN * 9 * 4;
-  constexpr int P_LOADS = (P_F4 + 255) / 256, W_LOADS = (W_F4 + 255) / 256;
-  constexpr int RPW = TH / 4;                       // pixel rows (16-pixel MFMA tiles) per wave
-  constexpr int KP = (RPW * WTN <= 3) ? 4 : (RPW * WTN <= 6) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float lds[PROWS * PSTR + BN * 9 * 16];
-  float* lp = lds;
-  float* lw = lds + PROWS * PSTR;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntn = p.N / BN;
-  const int nblk = gridDim.x;
-  const int wg = xcd_remap(blockIdx.x, nblk);
-  const int nt = wg % ntn;
-  int mt = wg / ntn;
-  const int tx = mt % p.tiles_x;
-  mt /= p.tiles_x;
-  const int ty = mt % p.tiles_y, b = mt / p.tiles_y;
-  const int y0 = ty * TH, x0 = tx * 16, n0 = nt * BN;
-
-  // per-thread load slots, fixed for the whole kernel (only the channel offset moves)
-  long p_off[P_LOADS];
-  int p_st[P_LOADS];
-#pragma unroll
-  for (int i = 0; i < P_LOADS; ++i) {
-    const int f = tid + 256 * i;
-    const int r = f >> 2, q = f & 3;
-    const int py = r / PW, px = r - py * PW;
-    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool ok = (f < P_F4) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-    p_off[i] = ok ? ((long)(b * p.H + iy) * p.W + ix) * p.ldx + 4 * q : -1;
-    p_st[i] = (f < P_F4) ? r * PSTR + 4 * q : -1;
-  }
-  long w_off[W_LOADS];
-  int w_st[W_LOADS];
-#pragma unroll
-  for (int i = 0; i < W_LOADS; ++i) {
-    const int f = tid + 256 * i;
-    const int r = f >> 2, q = f & 3;          // r = tap*BN + n
-    const int tap = r / BN, n = r - tap * BN;
-    w_off[i] = (f < W_F4) ? ((long)(n0 + n) * 9 + tap) * p.K + 4 * q : -1;
-    w_st[i] = (f < W_F4) ? r * 16 + 4 * lds_slot(n, q) : -1;
-  }
-
-  f32x4 rp[P_LOADS], rw[W_LOADS];
-  // load slot j of the combined list (patch slots first); part = tap index: the per-CU load path
-  // takes ~40 cycles per wave-wide 16-byte load, and a wave that issues its ten loads back to back
-  // sits blocked at the issue port for thousands of cycles (tools/ubench/patch_lab.hip) -- so the
-  // next stage's loads go out one or two per tap, between the MFMA runs.
-  auto stage_load_part = [&](int c0, int part, int nparts) {
-#pragma unroll
-    for (int i = 0; i < P_LOADS; ++i)
-      if (i % nparts == part) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p_off[i] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + p_off[i] + c0);
-        rp[i] = v;
-      }
-#pragma unroll
-    for (int i = 0; i < W_LOADS; ++i)
-      if ((P_LOADS + i) % nparts == part) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (w_off[i] >= 0) v = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + c0);
-        rw[i] = v;
-      }
-  };
-  auto stage_load = [&](int c0) { stage_load_part(c0, 0, 1); };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < P_LOADS; ++i)
-      if (p_st[i] >= 0) *reinterpret_cast<f32x4*>(lp + p_st[i]) = rp[i];
-#pragma unroll
-    for (int i = 0; i < W_LOADS; ++i)
-      if (w_st[i] >= 0) *reinterpret_cast<f32x4*>(lw + w_st[i]) = rw[i];
-  };
-
-  f32x4 acc[KP][WTN][RPW];
-#pragma unroll
-  for (int kp = 0; kp < KP; ++kp)
-#pragma unroll
-    for (int n = 0; n < WTN; ++n)
-#pragma unroll
-      for (int m = 0; m < RPW; ++m) acc[kp][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fi = lane & 15, fh = lane >> 4;
-  const int woff = fi * 16 + 4 * lds_slot(fi, fh);    // weight fragment (aligned 16-row tiles)
-  const int nchunks = p.K >> 4;
-  stage_load(0);
-  stage_store();
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (more) stage_load_part((c + 1) << 4, t, 9);
-      const int gt = p.flip ? 8 - t : t;
-      const int kh = gt / 3, kw = gt - 3 * kh;
-      f32x4 xf[RPW], wf[WTN];
-#pragma unroll
-      for (int m = 0; m < RPW; ++m)
-        xf[m] = *reinterpret_cast<const f32x4*>(lp + ((wave * RPW + m + kh) * PW + kw + fi) * PSTR + 4 * fh);
-#pragma unroll
-      for (int n = 0; n < WTN; ++n) wf[n] = *reinterpret_cast<const f32x4*>(lw + (t * BN + 16 * n) * 16 + woff);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int n = 0; n < WTN; ++n)
-#pragma unroll
-          for (int m = 0; m < RPW; ++m)
-            acc[k % KP][n][m] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[k % KP][n][m], 0, 0, 0);
-    }
-    __syncthreads();
-    if (more) stage_store();
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int m = 0; m < RPW; ++m) {
-    const int oy = y0 + wave * RPW + m, ox = x0 + fi;
-    if (oy >= p.H || ox >= p.W) continue;
-    float* yrow = p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy;
-#pragma unroll
-    for (int n = 0; n < WTN; ++n) {
-      const int ch = n0 + 16 * n + 4 * fh;
-      f32x4 v = acc[0][n][m];
-#pragma unroll
-      for (int kp = 1; kp < KP; ++kp) v += acc[kp][n][m];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
-      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
-      *reinterpret_cast<f32x4*>(yrow + ch) = v;
-    }
-  }
-}
-
-static int g_patch_mode = 0;   // 0 = off (default: measured no faster than im2col), 1 = automatic
-extern "C" int hrseg_debug_set_patch_mode(int mode) { g_patch_mode = mode; return 0; }
-
-// returns 1 if the problem is not a patch-kernel case (caller uses the im2col kernel)
-static int dispatch_patch(const IgemmArgs& a, int flip, hipStream_t st) {
-  if (!g_patch_mode || a.T != 9 || a.ntaps != 9 || a.sy != 1 || a.oys != 1 || a.Hi != a.Ho || a.Wi != a.Wo) return 1;
-  const int wtn = (a.N % 48 == 0) ? 3 : (a.N % 64 == 0) ? 4 : 0;
-  if (!wtn) return 1;
-  const int tiles_x = ceil_div(a.Wo, 16);
-  // tile rows: 8 when that still gives >= 2 blocks per CU and wastes < 15 % of the rows, else 4
-  const int ntn = a.N / (16 * wtn);
-  int th = 8;
-  if ((long)a.B * ceil_div(a.Ho, 8) * tiles_x * ntn < 512 || ceil_div(a.Ho, 8) * 8 > a.Ho * 1.15) th = 4;
-  const long blocks = (long)a.B * ceil_div(a.Ho, th) * tiles_x * ntn;
-  const double waste = (double)(ceil_div(a.Ho, th) * th) * (tiles_x * 16) / ((double)a.Ho * a.Wo);
-  if (blocks < 384 || waste > 1.35) return 1;       // small images: im2col + split-K does better
-  PatchArgs p;
-  p.x = a.x; p.w = a.w; p.bias = a.bias; p.y = a.y; p.ldx = a.ldx; p.ldy = a.ldy;
-  p.B = a.B; p.H = a.Ho; p.W = a.Wo; p.K = a.K; p.N = a.N;
-  p.tiles_x = tiles_x; p.tiles_y = ceil_div(a.Ho, th); p.flip = flip; p.accumulate = a.accumulate;
-  if (th == 8 && wtn == 3) hipLaunchKernelGGL((igemm_patch_kernel<8, 3>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else if (th == 8) hipLaunchKernelGGL((igemm_patch_kernel<8, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else if (wtn == 3) hipLaunchKernelGGL((igemm_patch_kernel<4, 3>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((igemm_patch_kernel<4, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  return 0;
-}
-
 // group dispatch: one common plan (64-pixel tiles, widest K stage, single LDS buffer); problems whose
 // channel tiling differs from the first one's, or that need a zero-fill they cannot get, make the
 // caller fall back to per-problem launches (return 1).
 static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
-extern "C" int hrseg_debug_set_group_wtm(int wtm) { g_group_wtm = wtm; return 0; }
 
 static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
@@ -780,7 +596,6 @@ struct WgradArgs {
   int ks, stride, T;
   int pix_per_block;  // multiple of the stage size
   float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
-  int row;            // 1: wgrad_row_body (3x3 stride 1): a block owns one kernel ROW (3 taps)
 };
 
 // Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
@@ -916,176 +731,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const
     }
 }
 
-// 3x3 stride-1 variant: a block owns one kernel ROW kh (taps kw = -1, 0, +1), a cout tile, a cin tile
-// and a pixel range.  Each stage loads the dy tile [64 px] and the x tile of the neighbour pixels
-// [66 px, shifted by kh image rows] ONCE and runs the three taps on them: the x operand of tap kw
-// for output pixel m is LDS row (m - first + kw + 1).  Same global loads per stage as the one-tap body,
-// three times the MFMAs: vector-memory instructions per MFMA drop 3x (they are what holds the
-// matrix pipe back).  Pixels at the left/right image border must not see the wrapped
-// neighbour: per-pixel masks (staged next to the tiles) zero the dy operand for kw = -1 / +1 there;
-// rows above/below the image are zero-filled at load time.
-template <int TN, int TK>
-__device__ __forceinline__ void wgrad_row_body(const WgradArgs& p, float* lds, const int bx, int id) {
-  constexpr int PIX = 64, BROWS = PIX + 2;
-  constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);
-  constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
-  float* la = lds;
-  float* lb = lds + PIX * SA;
-  float* lm = lb + BROWS * SB;                       // [2][PIX]: left-border / right-border masks
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
-  const int kt = id % nkt;
-  id /= nkt;
-  const int ct = id % nct;
-  const int khi = id / nct;                          // 0..2
-  const int n0 = ct * 16 * TN, k0 = kt * 16 * TK;
-  const int kh = khi - 1;
-  const int H = p.Ho, W = p.Wo, hw = H * W;
-
-  const int lo = bx * p.pix_per_block;
-  const int hi = min(lo + p.pix_per_block, p.M);
-  const int nstages = (hi - lo + PIX - 1) / PIX;
-  const int q = tid & 3, r0 = tid >> 2;
-
-  const int b_lo = max(lo - 1, 0) / hw;
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
-  const __amdgpu_buffer_rsrc_t rx =
-      make_rsrc(p.x + (size_t)b_lo * hw * p.ldx, (size_t)(p.B - b_lo) * hw * p.ldx * 4);
-
-  // byte offset of neighbour-space pixel pb (its image row shifted by kh), or OOB
-  auto x_off = [&](int pb) -> unsigned {
-    if (pb < 0 || pb >= p.M) return HRSEG_BUF_OOB;
-    const int b = fdiv(pb, hw, p.rcp_hw);
-    const int rem = pb - b * hw;
-    const int y = fdiv(rem, W, p.rcp_w), x = rem - y * W;
-    const int iy = y + kh;
-    if (iy < 0 || iy >= H) return HRSEG_BUF_OOB;
-    return ((unsigned)(((b - b_lo) * H + iy) * W + x) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u;
-  };
-
-  f32x4 ra[TN], rb[TK], rbx[TK];
-  float mL = 0.f, mR = 0.f;
-  auto stage_load = [&](int s) {
-    const int ml = s * PIX + r0;                     // row inside the block's range
-    const int m = lo + ml;
-    const bool ok = m < hi;
-    const unsigned dyo = ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) ra[j] = buf_load4(rdy, dyo, 64 * j);
-    const int b = fdiv(m, hw, p.rcp_hw);
-    const int rem = m - b * hw;
-    const int oy = fdiv(rem, W, p.rcp_w), ox = rem - oy * W;
-    mL = (ox != 0) ? 1.f : 0.f;
-    mR = (ox != W - 1) ? 1.f : 0.f;
-    const unsigned xo = x_off(m - 1);
-#pragma unroll
-    for (int j = 0; j < TK; ++j) rb[j] = buf_load4(rx, xo, 64 * j);
-    if (tid < 8) {                                   // the two extra neighbour rows of the stage
-      const unsigned xe = x_off(lo + s * PIX + PIX + (tid >> 2) - 1);
-#pragma unroll
-      for (int j = 0; j < TK; ++j) rbx[j] = buf_load4(rx, xe, 64 * j);
-    }
-  };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(la + r0 * SA + 16 * j + 4 * q) = ra[j];
-#pragma unroll
-    for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(lb + r0 * SB + 16 * j + 4 * q) = rb[j];
-    if (tid < 8) {
-#pragma unroll
-      for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(lb + (PIX + (tid >> 2)) * SB + 16 * j + 4 * q) = rbx[j];
-    }
-    if (q == 0) {
-      lm[r0] = mL;
-      lm[PIX + r0] = mR;
-    }
-  };
-
-  f32x4 acc[3][TN][TK];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k) acc[t][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (nstages > 0) {
-    stage_load(0);
-    stage_store();
-  }
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = s + 1 < nstages;
-    if (more) stage_load(s + 1);
-#pragma unroll
-    for (int ks4 = 0; ks4 < PIX / 16; ++ks4) {
-      const int row = wave * (PIX / 4) + ks4 * 4 + (lane >> 4);
-      float af[TN], afl[TN], afr[TN];
-      const float wl = lm[row], wr = lm[PIX + row];
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        af[n] = la[row * SA + 16 * n + (lane & 15)];
-        afl[n] = af[n] * wl;
-        afr[n] = af[n] * wr;
-      }
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        float bf[TK];
-#pragma unroll
-        for (int k = 0; k < TK; ++k) bf[k] = lb[(row + t) * SB + 16 * k + (lane & 15)];
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-          for (int k = 0; k < TK; ++k)
-            acc[t][n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? afl[n] : t == 2 ? afr[n] : af[n], bf[k],
-                                                                acc[t][n][k], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) stage_store();
-    __syncthreads();
-  }
-
-  // cross-wave reduction, one tap at a time: red[wave][tile][r*64 + lane]
-  const int r = tid >> 6, l = tid & 63;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lds[((wave * TN + n) * TK + k) * 256 + e * 64 + lane] = acc[t][n][k][e];
-    __syncthreads();
-    const int tap = khi * 3 + t;
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k) {
-        float v = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) v += lds[((wv * TN + n) * TK + k) * 256 + tid];
-        const int co = n0 + 16 * n + 4 * (l >> 4) + r;
-        const int ci = k0 + 16 * k + (l & 15);
-        atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
-      }
-    __syncthreads();
-  }
-}
-
-template <int TN, int TK>
-struct WgradRowLds {
-  static constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16), SB = 16 * TK + ((TK % 2) ? 0 : 16);
-  static constexpr int STAGE = 64 * SA + 66 * SB + 128, RED = 4 * TN * TK * 256;
-  static constexpr int FLOATS = (STAGE > RED) ? STAGE : RED;
-};
-template <int TN, int TK>
-__global__ __launch_bounds__(256) void wgrad_row_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[WgradRowLds<TN, TK>::FLOATS];
-  const int tiles = gridDim.y, nblk = gridDim.x * gridDim.y;
-  const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
-  wgrad_row_body<TN, TK>(p, lds, r / tiles, r % tiles);
-}
 
 template <int TN, int TK, int PIX, int DB>
 struct WgradLds {
@@ -1120,33 +765,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup grp) {
   const int r = xcd_remap(blockIdx.x - lo, nblk);
   wgrad_body<TN, TK, PIX, DB>(grp.a[g], lds, r / tiles, r % tiles);
 }
-
-template <int TN, int TK>
-__global__ __launch_bounds__(256) void wgrad_row_group_kernel(WgradGroup grp) {
-  __shared__ __attribute__((aligned(16))) float lds[WgradRowLds<TN, TK>::FLOATS];
-  int g = 0;
-  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
-  const int lo = g ? grp.blk_end[g - 1] : 0;
-  const int nblk = grp.blk_end[g] - lo;
-  const int tiles = nblk / grp.gx[g];
-  const int r = xcd_remap(blockIdx.x - lo, nblk);
-  wgrad_row_body<TN, TK>(grp.a[g], lds, r / tiles, r % tiles);
-}
-
 static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
-// opt-in (hrseg_debug_set_wgrad_row / HRSEG_WGRAD_ROW=1): 3x3 stride-1 convs with 48-channel tiles use
-// wgrad_row_body.  Measured equal to the one-tap body (group of the four branch convs 192 vs 183 us alone,
-// 90.4 vs 90.7 ms per train step): 3x fewer vector-memory instructions per MFMA buy nothing here, the
-// short kernels are bound by ramp-up, the cross-wave reduction and the atomics, not by the stage loop.
-static int g_wgrad_row = 0;
-extern "C" int hrseg_debug_set_wgrad_row(int on) { g_wgrad_row = on; return 0; }
-static bool wgrad_row_ok(const WgradArgs& a, int tn, int tk) {
-  return g_wgrad_row && a.ks == 3 && a.stride == 1 && tn == 3 && tk == 3;
-}
-extern "C" int hrseg_debug_set_wgrad_tune(int pix, int db, int target_blocks) {
-  g_tune_wg_pix = pix; g_tune_wg_db = db; g_tune_wg_blocks = target_blocks;
-  return 0;
-}
 
 // host-side check behind the 32-bit buffer offsets of wgrad_body: one block's pixel range
 static int check_wgrad_span(const WgradArgs& a) {
@@ -1173,32 +792,9 @@ static int launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
 }
 
 template <int TN, int TK>
-static int launch_wgrad_row(WgradArgs a, hipStream_t st) {
-  // three taps per block: a third of the tile sets, so the pixel ranges are cut finer for the same grid
-  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * 3;
-  int target = 7 * tiles;
-  if (target < 512) target = 512;
-  if (target > 4096) target = 4096;
-  if (g_tune_wg_blocks) target = g_tune_wg_blocks;
-  int ksplit = target / tiles;
-  if (ksplit < 1) ksplit = 1;
-  int ppb = ceil_div(ceil_div(a.M, ksplit), 64) * 64;
-  if (ppb < 2 * 64) ppb = 2 * 64;
-  a.pix_per_block = ppb;
-  a.row = 1;
-  if (int e = check_wgrad_span(a)) return e;
-  const int gx = ceil_div(a.M, ppb);
-  hipLaunchKernelGGL((wgrad_row_kernel<TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
-  return 0;
-}
-
-template <int TN, int TK>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   // measured (tools/wgrad_sweep.py): 64-pixel stages, single LDS buffer; grid of ~7 blocks per
   // output tile set, between 2 and 16 blocks per CU
-  if constexpr (TN == 3 && TK == 3) {
-    if (wgrad_row_ok(a, TN, TK)) return launch_wgrad_row<TN, TK>(a, st);
-  }
   const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
   int pix = 64, db = 1, target = 7 * tiles;
   if (target < 512) target = 512;
@@ -1213,12 +809,8 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 }
 
 static int g_wg_mult = 0, g_wg_min = 0, g_wg_max = 0;      // tuning overrides of the grouped weight-gradient grid
-extern "C" int hrseg_debug_set_wgrad_group_plan(int mult, int min_blocks, int max_blocks) {
-  g_wg_mult = mult; g_wg_min = min_blocks; g_wg_max = max_blocks;
-  return 0;
-}
 static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
-  tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * (a.row ? 3 : a.T);
+  tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
   // measured (tools/wgrad_group_plan.py, groups of 2-4 branch convs at 4 and 8 images): 2 pixel ranges per tile
   // set, at least 768 and at most 2048 blocks per problem -- 7 ranges per tile set left the 384-channel
   // problem with 4032 blocks of 8 stages whose cross-wave reduction and atomics cost as much as their MFMAs
@@ -1229,7 +821,7 @@ static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, in
   int ksplit = target / tiles;
   if (ksplit < 1) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), pix) * pix;
-  if (ppb < (a.row ? 2 : 4) * pix) ppb = (a.row ? 2 : 4) * pix;
+  if (ppb < 4 * pix) ppb = 4 * pix;
   a.pix_per_block = ppb;
   gx = ceil_div(a.M, ppb);
 }
@@ -1243,22 +835,15 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
   WgradGroup g;
   g.n = n;
   int end = 0;
-  bool row = true;
-  for (int i = 0; i < n; ++i) row = row && wgrad_row_ok(a[i], tn, tk);
   for (int i = 0; i < n; ++i) {
     if (a[i].Cout % (16 * tn) || a[i].Cin % (16 * tk)) return 1;
     int gx, tiles;
-    a[i].row = row ? 1 : 0;
     plan_wgrad_blocks(a[i], tn, tk, 64, gx, tiles);
     if (check_wgrad_span(a[i])) return 1;   // the per-problem launch reports the error
     g.gx[i] = gx;
     end += gx * tiles;
     g.blk_end[i] = end;
     g.a[i] = a[i];
-  }
-  if (row) {
-    hipLaunchKernelGGL((wgrad_row_group_kernel<3, 3>), dim3(end), dim3(256), 0, st, g);
-    return 0;
   }
 #define WGG(TN_, TK_) if (tn == TN_ && tk == TK_) hipLaunchKernelGGL((wgrad_group_kernel<TN_, TK_, 64, 1>), dim3(end), dim3(256), 0, st, g);
   WGG(3, 3) WGG(3, 4) WGG(4, 3) WGG(4, 4)
@@ -1470,10 +1055,6 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
-  if (dispatch_patch(a, 0, st) == 0) {
-    HRSEG_LAUNCH_CHECK("igemm_patch(fwd)");
-    return 0;
-  }
   if (int e = dispatch_igemm(a, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;
@@ -1499,10 +1080,6 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
     int oy[9], ox[9], wtp[9];
     for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
     pack_taps(a, a.T, oy, ox, wtp);
-    if (dispatch_patch(a, 1, st) == 0) {
-      HRSEG_LAUNCH_CHECK("igemm_patch(dgrad)");
-      return 0;
-    }
     if (int e = dispatch_igemm(a, st)) return e;
     HRSEG_LAUNCH_CHECK("igemm_conv(dgrad)");
     return 0;
@@ -1596,4 +1173,24 @@ extern "C" int hrseg_weight_transpose_all(const float* flat, float* flat_t, cons
                      table);
   HRSEG_LAUNCH_CHECK("weight_transpose_all");
   return 0;
+}
+
+// --------------------------------------------------------------------------- tuning knobs
+// One entry point for the tile-plan overrides the sweep tools under tools/ use (0 = automatic plan):
+//   igemm_wtm / igemm_kc / igemm_db / igemm_ksplit   fp32 implicit GEMM: pixel tiles per wave (1,2,4; +10 = 96-channel
+//                                                     tiles), 16-channel chunks per stage, LDS buffers, split-K factor
+//   group_wtm                                         grouped launches: 1 = 64-pixel, 2 = 128-pixel tiles
+//   wgrad_pix / wgrad_db / wgrad_blocks               weight gradient: pixels per stage, LDS buffers, target grid
+//   wgrad_group_mult / _min / _max                    grouped weight gradient: blocks per problem = clamp(mult*tiles, min, max)
+extern "C" int hrseg_tune(const char* key, int value) {
+  struct { const char* k; int* v; } tab[] = {
+      {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
+      {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
+      {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
+      {"wgrad_group_max", &g_wg_max}};
+  HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
+  for (auto& e : tab)
+    if (!strcmp(e.k, key)) { *e.v = value; return 0; }
+  hrseg_set_error("hrseg_tune: unknown key '%s'", key);
+  return HRSEG_ERR_INVALID_ARG;
 }

@@ -14,4 +14,4 @@ void hrseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hrseg_last_error_string(void) { return g_err; }
-extern "C" int hrseg_abi_version(void) { return 4; }
+extern "C" int hrseg_abi_version(void) { return 5; }

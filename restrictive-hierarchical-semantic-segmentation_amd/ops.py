@@ -197,24 +197,6 @@ def bn_bwd(dz, z, relu, y, coef, dgamma, dbeta, dres=None, dres_accumulate=False
     return dy
 
 
-_BN_SLOT = 4 * 2 * 1024          # doubles per problem slot: up to 4 segments x [2][C <= 1024]
-_bn_pools = {}
-# One-launch BN statistics (fp64 atomics into an accumulator + finalize by the last block).  Off by default:
-# measured on the hier HRNet-W48 step it is 1 ms SLOWER than partial sums + a finalize launch (forward statistics
-# kernel 32.8 us against 20.9 + 6.1 us: 256 blocks finishing together serialise on the same 2*C addresses).
-BN_ONE_LAUNCH = os.environ.get("HRSEG_BN_ONE_LAUNCH", "0") == "1"
-
-
-def _bn_pool(device):
-    """zero-initialised accumulators + ticket counters for the one-launch BN statistics (8 problem slots);
-    the kernels leave them zeroed and launches on one stream are ordered, so one pool per (device, stream)"""
-    key = (str(device), _lib.stream())
-    pool = _bn_pools.get(key)
-    if pool is None:
-        pool = _bn_pools[key] = (zeros((8 * _BN_SLOT,), torch.float64, device), zeros((8,), torch.int32, device))
-    return pool
-
-
 def bn_fwd_group(items, training):
     """items: list of dict(y, gamma, beta, rm, rv, nbt, momentum, eps, residual, relu[, out]);
     -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply)."""
@@ -236,10 +218,6 @@ def bn_fwd_group(items, training):
         a.momentum, a.eps = float(it["momentum"]), float(it["eps"])
         a.stat_updates = int(it.get("repeat", 1))
         a.stat_div = int(it.get("stat_div", 1))
-        if BN_ONE_LAUNCH and training and Cn <= 1024 and n <= 8:
-            acc, cnt = _bn_pool(y.device)
-            slot = len(outs)
-            a.acc, a.counter = acc.data_ptr() + 8 * _BN_SLOT * slot, cnt.data_ptr() + 4 * slot
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         if training:
@@ -270,10 +248,6 @@ def bn_bwd_group(items, eval_mode):
         part = torch.empty((nch + nseg) * 2 * Cn, dtype=torch.float64, device=y.device)
         keep.append(part)
         a.nseg = nseg
-        if BN_ONE_LAUNCH and Cn <= 1024 and nseg <= 4 and n <= 8:
-            acc, cnt = _bn_pool(y.device)
-            slot = len(keep) - 1
-            a.acc, a.counter = acc.data_ptr() + 8 * _BN_SLOT * slot, cnt.data_ptr() + 4 * slot
         dres = it.get("dres")
         a.dz, a.lddz = ptr(dz), _ld(dz)
         use_z = it["relu"] and z is not None      # z None: mask recomputed from y (forward without residual)

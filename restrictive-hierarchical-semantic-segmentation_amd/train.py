@@ -22,7 +22,7 @@ import torch
 
 from . import ops
 from .Metrics import losses
-from .Metrics.performance_metrics import METRIC_NAMES, metrics_from_confusion
+from .Metrics.performance_metrics import METRIC_NAMES, metrics_from_confusion, shared_confusion
 from .utils.hierarchy import get_classes  # noqa: F401  (API: train.get_classes)
 
 
@@ -164,8 +164,9 @@ def get_metrics(output, target, accuracy, IoU, dice, precision, recall, Accuracy
     for outs in range(len(output)):
         child = outs != 0
         clss_num = target[outs].shape[1]
-        for k in ("iou", "accuracy", "dice", "precision", "recall"):
-            new[k].append(fns[k](output[outs], target[outs], device, clss_num, child))
+        with shared_confusion():             # the five calls see the same tensors: one counting pass
+            for k in ("iou", "accuracy", "dice", "precision", "recall"):
+                new[k].append(fns[k](output[outs], target[outs], device, clss_num, child))
     vec = {k: torch.cat(v) for k, v in new.items()}
     perf_no_bg = vec["dice"][1:]
     if parent_metrics != []:

@@ -33,8 +33,7 @@ def test_header_symbols_exported_and_prototypes_match():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
-        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_debug_set_conv_tune", "hrseg_debug_set_wgrad_tune",
-                    "hrseg_debug_set_patch_mode", "hrseg_debug_set_wgrad_row", "hrseg_debug_set_group_wtm", "hrseg_debug_set_wgrad_group_plan"):
+        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune"):
             continue
         protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
         assert name in protos, f"{name} has no ctypes prototype"
@@ -44,7 +43,8 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == 4
+    assert _lib.abi_version() == _lib.ABI_VERSION == 5
+    assert not any(n.startswith("hrseg_debug_") for n in decls), "experimental switches do not belong in the public header"
 
 
 def test_invalid_arguments_are_reported_without_a_gpu():
@@ -55,3 +55,6 @@ def test_invalid_arguments_are_reported_without_a_gpu():
     rc = lib.hrseg_conv_fwd(None, None, None, None, ctypes.byref(shape), None)
     assert rc == -1
     assert b"does not match" in lib.hrseg_last_error_string()
+    lib.hrseg_tune.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    assert lib.hrseg_tune(b"igemm_wtm", 0) == 0
+    assert lib.hrseg_tune(b"no_such_knob", 1) == -1 and b"unknown key" in lib.hrseg_last_error_string()

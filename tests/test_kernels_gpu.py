@@ -75,28 +75,6 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
         assert rel(nchw(dx), 2 * xr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("case", [(48, 48, 3, 1, 37, 41, 2), (96, 96, 3, 1, 19, 23, 3), (48, 96, 3, 1, 7, 5, 3),
-                                  (96, 48, 3, 1, 1, 9, 2), (48, 48, 3, 1, 64, 1, 2), (144, 48, 3, 1, 13, 64, 1)])
-def test_wgrad_row_variant(ops, case):
-    """opt-in weight-gradient body that runs a kernel row (3 taps) per block: same result as autograd"""
-    from hrseg_amd import _lib
-    cin, cout, k, s, H, W, B = case
-    g = torch.Generator().manual_seed(sum(case) + 1)
-    x = torch.randn(B, cin, H, W, generator=g)
-    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_(True)
-    y = F.conv2d(x, w, padding=1)
-    dy = torch.randn(y.shape, generator=g)
-    y.backward(dy)
-    dw = torch.zeros(cout, k * k, cin, device="cuda")
-    _lib.set_wgrad_row(1)
-    try:
-        ops.conv_wgrad(nhwc(x), nhwc(dy), dw, k, s)
-        ops.conv_wgrad_group([nhwc(x), nhwc(x)], [nhwc(dy), nhwc(dy)], [dw, torch.zeros_like(dw)], k, s)
-    finally:
-        _lib.set_wgrad_row(0)
-    assert rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 5e-5
-
-
 def test_conv_beyond_2p24_pixels(ops):
     """tensors of 2^24 pixels or more take the integer-division index path (the float-reciprocal division is
     exact only below 2^24): forward, data gradient and weight gradient of a 3x3 conv on a 4100x4100 image"""
@@ -177,13 +155,10 @@ def test_batchnorm_eval_coef(ops):
     assert rel(nchw(z), F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)) < 1e-5
 
 
-@pytest.mark.parametrize("one_launch", [False, True])
-def test_batchnorm_group_fwd_bwd(ops, one_launch, monkeypatch):
+def test_batchnorm_group_fwd_bwd(ops):
     """grouped BN (statistics, finalize, apply; reduce, totals, apply): four problems of different size per
     launch, run twice, with and without residual; without residual the backward gets no z and recomputes
     the ReLU mask from y"""
-    # one_launch: statistics accumulated with fp64 atomics, finalize by the last block (opt-in HRSEG_BN_ONE_LAUNCH)
-    monkeypatch.setattr(ops, "BN_ONE_LAUNCH", one_launch)
     cfgs = [(48, 37, 41, 2, True), (96, 19, 20, 2, False), (384, 5, 6, 2, False), (192, 9, 9, 3, True)]
     g = torch.Generator().manual_seed(7)
     probs = []

@@ -39,17 +39,3 @@ for nb in (64, 128, 256, 512, 1024, 2048):
     _lib.set_wgrad_tune(0, 0, nb)
     print("  target blocks %5d: stem %8.1f us   unet inc %8.1f us" % (nb, timeit(lambda: ops.conv_wgrad(x, dy, dw, 3, 2)), timeit(lambda: ops.conv_wgrad(xu, dyu, dw, 3, 1))))
 _lib.set_wgrad_tune(0, 0, 0)
-
-# weight-gradient of the grouped branch convs: one tap per block vs a kernel row per block
-chans, sizes = [48, 96, 192, 384], [155, 78, 39, 20]
-xs = [torch.randn(B, h, h, c, device=dev) for c, h in zip(chans, sizes)]
-dys = [torch.randn(B, h, h, c, device=dev) for c, h in zip(chans, sizes)]
-dws = [torch.zeros(c, 9, c, device=dev) for c in chans]
-fl = sum(2.0 * B * h * h * c * c * 9 for c, h in zip(chans, sizes))
-for on in (0, 1):
-    _lib.set_wgrad_row(on)
-    t4 = timeit(lambda: ops.conv_wgrad_group(xs, dys, dws, 3, 1))
-    t1 = timeit(lambda: ops.conv_wgrad(xs[0], dys[0], dws[0], 3, 1))
-    print("wgrad row=%d: group of 4 %7.1f us (%5.1f TF)   48ch@155 alone %7.1f us (%5.1f TF)" % (
-        on, t4, fl / t4 / 1e6, t1, 2.0 * B * 155 * 155 * 48 * 48 * 9 / t1 / 1e6))
-_lib.set_wgrad_row(1)
