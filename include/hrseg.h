@@ -51,10 +51,19 @@ int hrseg_abi_version(void);
  * k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Cin, Cout multiples of 16
  * (implicit GEMM on v_mfma_f32_16x16x4_f32) except the stem-style Cin<=4 layer,
  * which hrseg_conv_fwd/wgrad route to direct kernels.                        */
+/* Arithmetic of the contraction (operands and results are fp32 in memory in every mode):
+ *   F32     fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 products)
+ *   BF16X3  each operand split exactly into 3 bf16 pieces, the 6 largest of the 9 piece products on
+ *           v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-grade (dropped terms < 2^-24 relative)
+ *           at 16/6 of the fp32 matrix rate
+ *   BF16X2  2 pieces, 3 products (operand error 2^-16)
+ *   BF16    operands rounded to bf16, fp32 accumulation (BASELINE configs[4] arithmetic)              */
+enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3 };
 typedef struct {
   int B, Hi, Wi, Cin, ldx; /* input  x[B,Hi,Wi,Cin], row stride ldx   */
   int Ho, Wo, Cout, ldy;   /* output y[B,Ho,Wo,Cout], row stride ldy  */
   int ksize, stride;       /* 1 or 3 ; 1 or 2                          */
+  int precision;           /* hrseg_conv_precision                     */
 } hrseg_conv_shape_t;
 
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */

@@ -31,7 +31,11 @@ _f = C.c_float
 
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
-    _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride")]
+    _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")]
+
+
+# hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
+CONV_PRECISION = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "bf16": 3}
 
 
 class BnFwd(C.Structure):

@@ -41,6 +41,7 @@ struct IgemmArgs {
   int accumulate;            // y += result
   float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
   int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
+  int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for
@@ -290,6 +291,21 @@ struct IgemmGroup {
   int ksplit[MAXG];
   IgemmArgs a[MAXG];
 };
+// weight-gradient problem (kernels further down)
+struct WgradArgs {
+  const float* x;   // [B,Hi,Wi,Cin] ldx
+  const float* dy;  // [B,Ho,Wo,Cout] lddy
+  float* dw;        // [Cout][T][Cin]
+  int ldx, lddy;
+  int B, Hi, Wi, Cin, Ho, Wo, Cout;
+  int M;            // B*Ho*Wo
+  int ks, stride, T;
+  int pix_per_block;  // multiple of the stage size
+  float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
+};
+
+#include "conv_sp.h"
+
 // FULL3X3 is a call-site tag only (same code): groups of full 3x3 stride-1 problems -- the parallel branch
 // convs, forward and data-gradient, the dominant launches of a step -- get their own kernel symbol, so
 // profiles list them apart from the small fuse-path / parity-class groups.
@@ -374,7 +390,14 @@ static int finalize_args(IgemmArgs& a) {
   a.rcp_hw = big ? 0.f : 1.0f / (float)(a.Ho * a.Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)a.Wo;
   a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
-  const double span = ((double)ceil_div(256, a.Ho * a.Wo) + 1.0) * a.Hi * a.Wi * (double)a.ldx * 4.0;
+  a.oy_min = a.ox_min = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    const int oy = (int)((a.offy_pk >> (4 * t)) & 15) - 8, ox = (int)((a.offx_pk >> (4 * t)) & 15) - 8;
+    if (oy < a.oy_min) a.oy_min = oy;
+    if (ox < a.ox_min) a.ox_min = ox;
+  }
+  const double span = ((double)ceil_div(256, a.Ho * a.Wo) + 1.0) * a.Hi * a.Wi * (double)a.ldx * 4.0 +
+                      (double)(2 * (-a.oy_min) * a.Wi + 2 * (-a.ox_min) + 16) * a.ldx * 4.0;
   const double wbytes = (double)a.N * a.T * a.K * 4.0;
   if (span >= 4294967296.0 || wbytes >= 4294967296.0) {
     hrseg_set_error("igemm: image of %dx%dx%d floats (or %g-byte weight) exceeds the 4 GB buffer-offset range",
@@ -384,9 +407,56 @@ static int finalize_args(IgemmArgs& a) {
   return 0;
 }
 
-static int dispatch_igemm(const IgemmArgs& a_in, hipStream_t st) {
+// ---- split-precision plan: 128-pixel tiles for large problems, 64 otherwise; split-K under 256 blocks
+static int g_sp_wtm = 0, g_sp_wtn = 0, g_sp_ksplit = 0;      // hrseg_tune overrides (0 = automatic)
+struct SpPlan { int wtm, wtn, ksplit; };
+static SpPlan plan_sp(const IgemmArgs& a) {
+  SpPlan pl;
+  pl.wtn = (a.N % 48 == 0) ? 3 : (a.N % 64 == 0) ? 4 : (a.N % 32 == 0) ? 2 : 1;
+  if (g_sp_wtn && a.N % (16 * g_sp_wtn) == 0) pl.wtn = g_sp_wtn;
+  const int ntn = a.N / (16 * pl.wtn);
+  pl.wtm = ((long)ceil_div(a.M, 128) * ntn >= 512) ? 2 : 1;
+  if (g_sp_wtm) pl.wtm = g_sp_wtm;
+  const long blocks = (long)ceil_div(a.M, 64 * pl.wtm) * ntn;
+  const int nslabs = (a.ntaps * (a.K / 16) + 1) / 2;
+  pl.ksplit = 1;
+  if (blocks < 256) {
+    pl.ksplit = (int)((448 + blocks - 1) / blocks);
+    if (pl.ksplit > nslabs / 8) pl.ksplit = nslabs / 8;
+  }
+  if (g_sp_ksplit) pl.ksplit = g_sp_ksplit;
+  if (pl.ksplit > nslabs) pl.ksplit = nslabs;
+  if (pl.ksplit < 1) pl.ksplit = 1;
+  if (!(a.accumulate || (a.ldy == a.N && a.oys == 1 && a.oxs == 1))) pl.ksplit = 1;
+  return pl;
+}
+
+template <int NS>
+static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
+#define SP2(M_, N_) \
+  if (pl.wtm == M_ && pl.wtn == N_) { \
+    hipLaunchKernelGGL((igemm_sp_kernel<NS, M_, N_>), dim3(ceil_div(a.M, 64 * M_) * (a.N / (16 * N_)), pl.ksplit), dim3(256), 0, st, a); \
+    return 0; }
+#define SP1(M_) SP2(M_, 1) SP2(M_, 2) SP2(M_, 3) SP2(M_, 4) SP2(M_, 6)
+  SP1(1) SP1(2) SP1(4)
+#undef SP1
+#undef SP2
+  hrseg_set_error("igemm_sp: no kernel for plan wtm=%d wtn=%d", pl.wtm, pl.wtn);
+  return HRSEG_ERR_UNSUPPORTED;
+}
+
+static int sp_pieces(int precision) {    // hrseg_conv_precision -> bf16 pieces per operand (0: the fp32 MFMA kernels)
+  return precision == HRSEG_CONV_BF16X3 ? 3 : precision == HRSEG_CONV_BF16X2 ? 2 : precision == HRSEG_CONV_BF16 ? 1 : 0;
+}
+
+static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
   IgemmArgs a = a_in;
   if (int e = finalize_args(a)) return e;
+  if (const int ns = sp_pieces(precision)) {
+    const SpPlan pl = plan_sp(a);
+    if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
+    return ns == 3 ? launch_sp<3>(a, pl, st) : ns == 2 ? launch_sp<2>(a, pl, st) : launch_sp<1>(a, pl, st);
+  }
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
 #define IG4(M_, N_, K_, D_) \
@@ -408,11 +478,32 @@ static int dispatch_igemm(const IgemmArgs& a_in, hipStream_t st) {
 // caller fall back to per-problem launches (return 1).
 static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
 
-static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
+template <int NS>
+static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, hipStream_t st) {
+  bool full = true;
+  for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
+  const dim3 grid(g.blk_end[g.n - 1]);
+#define SPG(M_, N_) \
+  if (wtm == M_ && wtn == N_) { \
+    if (full) hipLaunchKernelGGL((igemm_sp_group_kernel<NS, M_, N_, true>), grid, dim3(256), 0, st, g); \
+    else hipLaunchKernelGGL((igemm_sp_group_kernel<NS, M_, N_, false>), grid, dim3(256), 0, st, g); \
+    return 0; }
+  SPG(1, 3) SPG(1, 4) SPG(1, 6) SPG(2, 3) SPG(2, 4) SPG(2, 6)
+#undef SPG
+  return 1;
+}
+
+static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
-  const int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
-  const int kc = (a[0].K % 48 == 0) ? 3 : (a[0].K % 32 == 0) ? 2 : 1;
+  const int ns = sp_pieces(precision);
+  int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
+  const int kc = ns ? 1 : (a[0].K % 48 == 0) ? 3 : (a[0].K % 32 == 0) ? 2 : 1;
   if (!wtn) return 1;
+  if (ns && g_sp_wtn) {
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && a[i].N % (16 * g_sp_wtn) == 0;
+    if (ok && (g_sp_wtn == 3 || g_sp_wtn == 4 || g_sp_wtn == 6)) wtn = g_sp_wtn;
+  }
   IgemmGroup g;
   g.n = n;
   for (int i = 0; i < n; ++i)
@@ -420,15 +511,17 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
   // per-problem split-K, then order the problems by stages per block, longest first: the blocks
   // that run longest must not be the ones dispatched last (the grid's tail)
   int tiles[MAXG], ks[MAXG], work[MAXG], order[MAXG];
-  const int wtm = g_group_wtm ? g_group_wtm : 1;
+  const int wtm = ns ? (g_sp_wtm ? g_sp_wtm : 2) : (g_group_wtm ? g_group_wtm : 1);
+  if (ns && wtm > 2) return 1;
   for (int i = 0; i < n; ++i) {
     tiles[i] = ceil_div(a[i].M, 64 * wtm) * (a[i].N / (16 * wtn));
-    const int nstages = a[i].ntaps * (a[i].K / (16 * kc));
+    const int nstages = ns ? (a[i].ntaps * (a[i].K / 16) + 1) / 2 : a[i].ntaps * (a[i].K / (16 * kc));
     ks[i] = 1;
     const bool can_split = a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1);
     if (can_split && tiles[i] < 512) {
       ks[i] = ceil_div(512, tiles[i]);
-      if (ks[i] > nstages / 12) ks[i] = nstages / 12;
+      const int min_stages = ns ? 8 : 12;        // stages (fp32: 16*kc channels; split precision: 32-channel slabs) per slice
+      if (ks[i] > nstages / min_stages) ks[i] = nstages / min_stages;
       if (ks[i] < 1) ks[i] = 1;
     }
     if (ks[i] > 1 && !a[i].accumulate) zero_f32(a[i].y, (size_t)a[i].B * a[i].Hy * a[i].Wy * a[i].N, st);
@@ -448,6 +541,8 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, hipStream_t st) {
     g.a[o] = a[i];
     if (finalize_args(g.a[o])) return 1;   // per-problem launches report the error
   }
+  if (ns) return ns == 3 ? launch_sp_group<3>(g, wtm, wtn, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, st)
+                                                                            : launch_sp_group<1>(g, wtm, wtn, st);
   if (wtm == 2 && wtn == 3 && kc == 3) launch_igemm_group<2, 3, 3, 1>(g, st);
   else if (wtm == 2 && wtn == 3) launch_igemm_group<2, 3, 1, 1>(g, st);
   else if (wtm == 2) return 1;
@@ -586,17 +681,6 @@ __global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* 
 }
 
 // --------------------------------------------------------------------------- wgrad on MFMA
-struct WgradArgs {
-  const float* x;   // [B,Hi,Wi,Cin] ldx
-  const float* dy;  // [B,Ho,Wo,Cout] lddy
-  float* dw;        // [Cout][T][Cin]
-  int ldx, lddy;
-  int B, Hi, Wi, Cin, Ho, Wo, Cout;
-  int M;            // B*Ho*Wo
-  int ks, stride, T;
-  int pix_per_block;  // multiple of the stage size
-  float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
-};
 
 // Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
 // the stage's pixels (the MFMA k dimension), so each wave accumulates the full TN x TK tile set and
@@ -808,6 +892,35 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   return launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
 }
 
+template <int NS, int TN, int TK>
+static int launch_wgrad_sp(WgradArgs a, hipStream_t st) {
+  constexpr int PIX = SpWgradLds<NS, TN, TK>::PIX;
+  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
+  int target = 7 * tiles;
+  if (target < 512) target = 512;
+  if (target > 4096) target = 4096;
+  if (g_tune_wg_blocks) target = g_tune_wg_blocks;
+  int ksplit = target / tiles;
+  if (ksplit < 1) ksplit = 1;
+  int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
+  if (ppb < 2 * PIX) ppb = 2 * PIX;
+  a.pix_per_block = ppb;
+  if (int e = check_wgrad_span(a)) return e;
+  const int gx = ceil_div(a.M, ppb);
+  hipLaunchKernelGGL((wgrad_sp_kernel<NS, TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
+  return 0;
+}
+template <int NS>
+static int dispatch_wgrad_sp(const WgradArgs& a, hipStream_t st) {
+  int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+  int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
+#define WS(TN_, TK_) if (tn == TN_ && tk == TK_) return launch_wgrad_sp<NS, TN_, TK_>(a, st);
+  WS(1, 1) WS(1, 2) WS(1, 3) WS(1, 4) WS(2, 1) WS(2, 2) WS(2, 3) WS(2, 4)
+  WS(3, 1) WS(3, 2) WS(3, 3) WS(3, 4) WS(4, 1) WS(4, 2) WS(4, 3) WS(4, 4)
+#undef WS
+  return HRSEG_ERR_UNSUPPORTED;
+}
+
 static int g_wg_mult = 0, g_wg_min = 0, g_wg_max = 0;      // tuning overrides of the grouped weight-gradient grid
 static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, int& tiles) {
   tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
@@ -893,6 +1006,8 @@ __global__ void weight_transpose_all_kernel(const float* __restrict__ flat, floa
 static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(s != nullptr, "%s: null shape", who);
   HRSEG_CHECK_ARG(s->ksize == 1 || s->ksize == 3, "%s: ksize %d not in {1,3}", who, s->ksize);
+  HRSEG_CHECK_ARG(s->precision >= HRSEG_CONV_F32 && s->precision <= HRSEG_CONV_BF16, "%s: precision %d is not a hrseg_conv_precision",
+                  who, s->precision);
   HRSEG_CHECK_ARG(s->stride == 1 || s->stride == 2, "%s: stride %d not in {1,2}", who, s->stride);
   HRSEG_CHECK_ARG(s->B > 0 && s->Hi > 0 && s->Wi > 0 && s->Cin > 0 && s->Cout > 0, "%s: non-positive dims", who);
   const int pad = (s->ksize - 1) / 2;
@@ -968,12 +1083,12 @@ extern "C" int hrseg_conv_fwd_group(int n, const float* const* x, const float* c
   bool ok = n <= MAXG;
   for (int i = 0; i < n; ++i) {
     if (int e = check_shape(&shapes[i], "hrseg_conv_fwd_group")) return e;
-    ok = ok && mfma_shape(&shapes[i]);
+    ok = ok && mfma_shape(&shapes[i]) && shapes[i].precision == shapes[0].precision;
   }
   if (ok && n >= 2) {
     IgemmArgs a[MAXG];
     for (int i = 0; i < n; ++i) fill_fwd_args(a[i], x[i], w[i], bias ? bias[i] : nullptr, y[i], &shapes[i]);
-    if (dispatch_igemm_group(a, n, st) == 0) {
+    if (dispatch_igemm_group(a, n, shapes[0].precision, st) == 0) {
       HRSEG_LAUNCH_CHECK("igemm_group(fwd)");
       return 0;
     }
@@ -991,12 +1106,12 @@ extern "C" int hrseg_conv_dgrad_group(int n, const float* const* dy, const float
   bool ok = n <= MAXG;
   for (int i = 0; i < n; ++i) {
     if (int e = check_shape(&shapes[i], "hrseg_conv_dgrad_group")) return e;
-    ok = ok && mfma_shape(&shapes[i]) && shapes[i].stride == 1;
+    ok = ok && mfma_shape(&shapes[i]) && shapes[i].stride == 1 && shapes[i].precision == shapes[0].precision;
   }
   if (ok && n >= 2) {
     IgemmArgs a[MAXG];
     for (int i = 0; i < n; ++i) fill_dgrad_s1_args(a[i], dy[i], wt[i], dx[i], accumulate[i], &shapes[i]);
-    if (dispatch_igemm_group(a, n, st) == 0) {
+    if (dispatch_igemm_group(a, n, shapes[0].precision, st) == 0) {
       HRSEG_LAUNCH_CHECK("igemm_group(dgrad)");
       return 0;
     }
@@ -1055,7 +1170,7 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
-  if (int e = dispatch_igemm(a, st)) return e;
+  if (int e = dispatch_igemm(a, s->precision, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;
 }
@@ -1080,7 +1195,7 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
     int oy[9], ox[9], wtp[9];
     for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
     pack_taps(a, a.T, oy, ox, wtp);
-    if (int e = dispatch_igemm(a, st)) return e;
+    if (int e = dispatch_igemm(a, s->precision, st)) return e;
     HRSEG_LAUNCH_CHECK("igemm_conv(dgrad)");
     return 0;
   }
@@ -1108,12 +1223,12 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
       pack_taps(c, n, oy, ox, wtp);
       cls[ncls++] = c;
     }
-  if (ncls >= 2 && dispatch_igemm_group(cls, ncls, st) == 0) {
+  if (ncls >= 2 && dispatch_igemm_group(cls, ncls, s->precision, st) == 0) {
     HRSEG_LAUNCH_CHECK("igemm_group(dgrad s2)");
     return 0;
   }
   for (int i = 0; i < ncls; ++i) {
-    if (int e = dispatch_igemm(cls[i], st)) return e;
+    if (int e = dispatch_igemm(cls[i], s->precision, st)) return e;
     HRSEG_LAUNCH_CHECK("igemm_conv(dgrad s2)");
   }
   return 0;
@@ -1147,6 +1262,11 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   const bool big = (long)s->B * s->Ho * s->Wo >= (1L << 24);   // float-reciprocal division is exact below 2^24
   a.rcp_hw = big ? 0.f : 1.0f / (float)(s->Ho * s->Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
+  if (const int ns = sp_pieces(s->precision)) {
+    if (int e = ns == 3 ? dispatch_wgrad_sp<3>(a, st) : ns == 2 ? dispatch_wgrad_sp<2>(a, st) : dispatch_wgrad_sp<1>(a, st)) return e;
+    HRSEG_LAUNCH_CHECK("wgrad_sp");
+    return 0;
+  }
   const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
   const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
 #define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { if (int e = launch_wgrad<TN_, TK_>(a, st)) return e; }
@@ -1187,7 +1307,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}};
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.v = value; return 0; }

@@ -1,0 +1,474 @@
+// Split-precision implicit GEMM on the bf16 matrix pipe (gfx950), included by conv.hip.
+//
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 value splits EXACTLY into three bf16
+// pieces (8 significand bits each: hi = truncate(x), mid = truncate(x - hi), lo = x - hi - mid), so an fp32
+// product is the sum of nine bf16 products of which the three smallest (mid*lo, lo*mid, lo*lo, each below
+// 2^-24 of the full product) are dropped: six v_mfma_f32_16x16x32_bf16 with fp32 accumulation per tile and
+// K step of 32 do the work of eight fp32 MFMAs in 6/16 of their time ("bf16x3", NS = 3: fp32-grade results).
+// NS = 2 keeps two pieces / three products (operand error 2^-16), NS = 1 is plain bf16 inputs with fp32
+// accumulation (BASELINE configs[4] arithmetic).  Activations and weights stay fp32 in HBM; the split
+// happens on the fly (v_perm_b32 packs two truncated values, v_and + v_sub form the residual).
+//
+// Measured on MI355X (tools/ubench/bf16_rate.hip): split + MFMA loop, two waves per SIMD: NS=3 298-323 TFLOP/s
+// fp32-equivalent (1.8-1.9 PFLOP/s on the matrix pipe), NS=2 535-562, NS=1 1355; the K=16 form
+// v_mfma_f32_16x16x16_bf16 runs at HALF the FLOP rate of 16x16x32, so only the K=32 form is used and the
+// reduction index runs over 32-wide slabs of the flattened (tap, 16-channel chunk) list.
+//
+// Layout of one block (256 threads, 4 waves): GEMM rows = 64*WTM output pixels, each wave owns 16*WTM of
+// them; columns = 16*WTN output channels.  The PIXEL operand never touches LDS: lane (r = l&15, g = l>>4)
+// loads, for its own pixel row r of every 16-row tile, channels 4g..4g+3 of the slab's two 16-channel units
+// (two 16-byte buffer loads), splits them in registers and has the MFMA B fragment (k = 8g..8g+7) in place.
+// Only the WEIGHT slab goes through LDS (all four waves read every weight fragment): [piece][row][64 B],
+// XOR-swizzled 16-byte slots, double buffered, one barrier per slab.  The k index inside a slab is
+// permuted the same way on both operands: k = 8g+j  <->  unit j>>2, channel 4g + (j&3).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> one dword of two bf16 (element 0 in the low half): truncation (exact residual arithmetic)
+__device__ __forceinline__ unsigned sp_pack_trunc(float lo, float hi) {
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+// ... round to nearest even (the last piece when fewer than three pieces are kept)
+__device__ __forceinline__ unsigned sp_pack_rne(float lo, float hi) {
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float sp_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
+// 8 fp32 (two f32x4: k = 0..3 and 4..7 of this lane's fragment) -> NS bf16x8 fragments
+template <int NS>
+__device__ __forceinline__ void sp_split8(const f32x4& a, const f32x4& b, bf16x8 (&out)[NS]) {
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4 u;
+    const bool last = s == NS - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      u[j] = (last && NS < 3) ? sp_pack_rne(x[2 * j], x[2 * j + 1]) : sp_pack_trunc(x[2 * j], x[2 * j + 1]);
+    out[s] = __builtin_bit_cast(bf16x8, u);
+    if (!last) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] -= sp_trunc(x[j]);
+    }
+  }
+}
+// 4 fp32 -> NS x 4 bf16 (8 bytes per piece): the weight staging granule
+template <int NS>
+__device__ __forceinline__ void sp_split4(const f32x4& a, u32x2 (&out)[NS]) {
+  float x[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const bool last = s == NS - 1;
+    if (last && NS < 3) out[s] = u32x2{sp_pack_rne(x[0], x[1]), sp_pack_rne(x[2], x[3])};
+    else out[s] = u32x2{sp_pack_trunc(x[0], x[1]), sp_pack_trunc(x[2], x[3])};
+    if (!last) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] -= sp_trunc(x[j]);
+    }
+  }
+}
+
+// acc += W-fragment pieces x X-fragment pieces: the products whose weight is at least 2^-16 of the full product
+template <int NS>
+__device__ __forceinline__ f32x4 sp_mma(const bf16x8 (&w)[NS], const bf16x8 (&x)[NS], f32x4 acc) {
+  if (NS == 3) {   // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], acc, 0, 0, 0);
+  }
+  if (NS >= 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc, 0, 0, 0);
+}
+
+template <int NS, int WTN>
+struct SpLds {
+  static constexpr int BN = 16 * WTN;
+  static constexpr int PIECE = BN * 64;          // bytes: one slab of one piece, [BN rows][32 bf16]
+  static constexpr int STAGE = NS * PIECE;       // one buffer
+  static constexpr int BYTES = 2 * STAGE;        // double buffered
+};
+
+// One output tile of one convolution.  `ks_idx / ks_n`: split-K slice of the slab list (partial sums are
+// added with fp32 atomics, as in igemm_body).
+template <int NS, int WTM, int WTN>
+__device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char* lds, const int bid, const int nblk,
+                                              const int ks_idx, const int ks_n) {
+  constexpr int BM = 64 * WTM, BN = 16 * WTN;
+  constexpr int PIECE = SpLds<NS, WTN>::PIECE, STAGE = SpLds<NS, WTN>::STAGE;
+  constexpr int WG = BN * 8;                       // 16-byte weight granules per slab
+  constexpr int W_LOADS = (WG + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = p.N / BN;
+  const int wg = xcd_remap(bid, nblk);
+  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+
+  // reduction index: units of 16 channels, u = tap * kch + chunk; a slab = units 2s, 2s+1
+  const int kch = p.K >> 4;
+  const int nunits = p.ntaps * kch;
+  const int nslabs_all = (nunits + 1) >> 1;
+  const int per = (nslabs_all + ks_n - 1) / ks_n;
+  const int s_lo = ks_idx * per;
+  const int s_hi = min(s_lo + per, nslabs_all);
+  const int nslabs = s_hi - s_lo;
+
+  // Input descriptor: based at the first image this tile touches, moved back by the most negative tap
+  // offset, so that every lane offset and every per-tap scalar offset is non-negative.  Memory in front of
+  // the tensor is never read: taps outside the image get the out-of-range offset (zero fill).
+  const int hw = p.Ho * p.Wo;
+  const int b0 = m0 / hw;
+  const long tap0 = (long)p.oy_min * p.Wi + p.ox_min;          // <= 0
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + ((long)b0 * p.Hi * p.Wi + tap0) * p.ldx,
+                                              (size_t)((long)(p.B - b0) * p.Hi * p.Wi - tap0) * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (size_t)p.N * p.T * p.K * 4);
+
+  // this lane's pixel rows: byte offset of (pixel at tap offset 0, channel 4g) and the taps that fall outside
+  unsigned voff[WTM];
+  int inval[WTM];
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    const int row = m0 + wave * 16 * WTM + 16 * m + r16;
+    if (row < p.M) {
+      const int b = fdiv(row, hw, p.rcp_hw);
+      const int rem = row - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.sy, ix0 = ox * p.sx;
+      voff[m] = ((unsigned)((b - b0) * p.Hi * p.Wi + iy0 * p.Wi + ix0) * (unsigned)p.ldx + 4u * g) * 4u;
+      int bad = 0;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int iy = iy0 + (int)((p.offy_pk >> (4 * t)) & 15) - 8, ix = ix0 + (int)((p.offx_pk >> (4 * t)) & 15) - 8;
+        bad |= ((iy < 0) | (iy >= p.Hi) | (ix < 0) | (ix >= p.Wi)) ? (1 << t) : 0;
+      }
+      inval[m] = bad;
+    } else {
+      voff[m] = 0;
+      inval[m] = -1;
+    }
+  }
+
+  // weight granules of this thread: granule f = (row n = f>>3, unit (f>>2)&1, 4-channel group f&3)
+  unsigned wbase[W_LOADS];
+  int wunit[W_LOADS], wst[W_LOADS];
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    const int f = tid + 256 * i;
+    const int n = f >> 3, unit = (f >> 2) & 1, gq = f & 3;
+    wbase[i] = (f < WG) ? ((unsigned)(n0 + n) * (unsigned)(p.T * p.K) + 4u * gq) * 4u : HRSEG_BUF_OOB;
+    wunit[i] = unit;
+    wst[i] = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
+  }
+
+  // running unit counters (scalar): tap and chunk of the next slab's two units
+  int u_next = 2 * s_lo;
+  f32x4 ra[WTM][2], rwt[W_LOADS];
+  auto issue_loads = [&]() {
+    unsigned soff[2], wsoff[2];
+    int tapbit[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = u_next + h;
+      const bool live = u < nunits;
+      const int t = live ? u / kch : 0;
+      const int c = u - t * kch;
+      const int dy = (int)((p.offy_pk >> (4 * t)) & 15) - 8 - p.oy_min, dx = (int)((p.offx_pk >> (4 * t)) & 15) - 8 - p.ox_min;
+      soff[h] = (unsigned)((dy * p.Wi + dx) * p.ldx + 16 * c) * 4u;
+      wsoff[h] = live ? (unsigned)((int)((p.wtap_pk >> (4 * t)) & 15) * p.K + 16 * c) * 4u : HRSEG_BUF_OOB;
+      tapbit[h] = live ? t : 31;          // bit 31 of inval is set only for rows past M; dead unit: forced below
+      if (!live) soff[h] = 0;
+    }
+    const bool live1 = u_next + 1 < nunits;
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // -1 (out of range: zero fill) when the tap is outside the image for this row or the unit is dead
+        const int oob = __builtin_amdgcn_sbfe(inval[m], tapbit[h], 1) | ((h == 1 && !live1) ? -1 : 0);
+        ra[m][h] = buf_load4(rx, voff[m] | (unsigned)oob, (int)soff[h]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const unsigned so = wunit[i] ? wsoff[1] : wsoff[0];
+      const unsigned off = (wbase[i] == HRSEG_BUF_OOB || so == HRSEG_BUF_OOB) ? HRSEG_BUF_OOB : wbase[i] + so;
+      rwt[i] = buf_load4(rw, off, 0);
+    }
+    u_next += 2;
+  };
+
+  bf16x8 xf[WTM][NS];
+  auto split_store = [&](int buf) {
+    unsigned char* base = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      u32x2 pc[NS];
+      sp_split4<NS>(rwt[i], pc);
+      if (tid + 256 * i < WG) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(base + s * PIECE + wst[i]) = pc[s];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) sp_split8<NS>(ra[m][0], ra[m][1], xf[m]);
+  };
+
+  f32x4 acc[WTN][WTM];
+#pragma unroll
+  for (int n = 0; n < WTN; ++n)
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int foff = r16 * 64 + lds_slot(r16, g) * 16;       // weight fragment of this lane inside a 16-row tile
+
+  if (nslabs > 0) {
+    issue_loads();
+    split_store(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nslabs; ++s) {
+    const bool more = s + 1 < nslabs;
+    if (more) issue_loads();
+    const unsigned char* base = lds + (s & 1) * STAGE;
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      bf16x8 wf[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
+#pragma unroll
+      for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma<NS>(wf, xf[m], acc[n][m]);
+    }
+    if (more) split_store((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds channels n0+16n+4g..+3 of pixel row r16 of every tile
+  const bool split = ks_n > 1;
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    const int row = m0 + wave * 16 * WTM + 16 * m + r16;
+    if (row >= p.M) continue;
+    size_t pix = row;
+    if (!p.direct_out) {
+      const int b = fdiv(row, hw, p.rcp_hw);
+      const int rem = row - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
+    }
+    float* yrow = p.y + pix * p.ldy;
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      const int ch = n0 + 16 * n + 4 * g;
+      f32x4 v = acc[n][m];
+      if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (split) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
+      } else {
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        *reinterpret_cast<f32x4*>(yrow + ch) = v;
+      }
+    }
+  }
+}
+
+template <int NS, int WTM, int WTN>
+__global__ __launch_bounds__(256) void igemm_sp_kernel(IgemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpLds<NS, WTN>::BYTES];
+  igemm_sp_body<NS, WTM, WTN>(p, lds, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+}
+
+// grouped form: see igemm_group_kernel
+template <int NS, int WTM, int WTN, bool FULL3X3>
+__global__ __launch_bounds__(256) void igemm_sp_group_kernel(IgemmGroup grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpLds<NS, WTN>::BYTES];
+  int gi = 0;
+  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
+  const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
+  const int tiles = grp.tiles[gi];
+  igemm_sp_body<NS, WTM, WTN>(grp.a[gi], lds, local % tiles, tiles, local / tiles, grp.ksplit[gi]);
+}
+
+// --------------------------------------------------------------------------- weight gradient
+// dW[co][t][ci] += sum_pix dy[pix][co] * x[pix_t][ci] on the bf16 matrix pipe.  Block = (tap, 16*TN couts,
+// 16*TK cins, pixel range) as in wgrad_body; a stage is 128 pixels, 32 per wave = one K step of the MFMA.
+// Both operands run over PIXELS in the reduction index, which is the strided direction of NHWC memory, so
+// both tiles are staged (split on the fly) as [pixel][channel] bf16 images in LDS and read back TRANSPOSED
+// with ds_read_b64_tr_b16: a 16-lane group fetches 4 pixel rows x 16 channels and every lane receives its
+// channel's 4 pixels.  Two such reads make one K=32 fragment; lane group g takes pixels 4g..4g+3 and
+// 16+4g..16+4g+3 of the wave's 32 (the same permutation on both operands), which keeps the two groups of
+// a 32-lane half on different bank rows when the row stride is an odd multiple of 32 bytes.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 sp_tr_read(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+constexpr int sp_row_stride(int channels) {       // bytes per pixel row: 2*channels rounded up to 32 * odd
+  int s = (2 * channels + 31) / 32;
+  if (s % 2 == 0) ++s;
+  return 32 * s;
+}
+
+template <int NS, int TN, int TK>
+struct SpWgradLds {
+  static constexpr int PIX = 128;
+  static constexpr int SA = sp_row_stride(16 * TN), SB = sp_row_stride(16 * TK);
+  static constexpr int PIECE = PIX * (SA + SB);
+  static constexpr int STAGE = NS * PIECE;
+  static constexpr int RED = 4 * TK * 256 * 4;            // cross-wave reduction, one row of tiles at a time
+  static constexpr int BYTES = (STAGE > RED) ? STAGE : RED;
+};
+
+template <int NS, int TN, int TK>
+__device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char* lds, const int bx, int id) {
+  using L = SpWgradLds<NS, TN, TK>;
+  constexpr int PIX = L::PIX, SA = L::SA, SB = L::SB, PIECE = L::PIECE;
+  constexpr int ROWS = PIX / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
+  const int kt = id % nkt;
+  id /= nkt;
+  const int ct = id % nct;
+  const int tap = id / nct;
+  const int n0 = ct * 16 * TN, k0 = kt * 16 * TK;
+  const int pad = (p.ks - 1) / 2;
+  const int kh = tap / p.ks - pad, kw = tap % p.ks - pad;
+
+  const int lo = bx * p.pix_per_block;
+  const int hi = min(lo + p.pix_per_block, p.M);
+  const int nstages = (hi - lo + PIX - 1) / PIX;
+  const int q = tid & 3, r0 = tid >> 2;
+
+  const int hw = p.Ho * p.Wo;
+  const int b_lo = lo / hw;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc(p.x + (size_t)b_lo * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b_lo) * p.Hi * p.Wi * p.ldx * 4);
+
+  f32x4 ra[ROWS][TN], rb[ROWS][TK];
+  auto stage_load = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int ml = s * PIX + r0 + 64 * i;
+      const int m = lo + ml;
+      const bool ok = m < hi;
+      const unsigned dyo = ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) ra[i][j] = buf_load4(rdy, dyo, 64 * j);
+      const int b = fdiv(m, hw, p.rcp_hw);
+      const int rem = m - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
+      const bool okx = ok & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      const unsigned xo =
+          okx ? ((unsigned)(((b - b_lo) * p.Hi + iy) * p.Wi + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u
+              : HRSEG_BUF_OOB;
+#pragma unroll
+      for (int j = 0; j < TK; ++j) rb[i][j] = buf_load4(rx, xo, 64 * j);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int r = r0 + 64 * i;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        u32x2 pc[NS];
+        sp_split4<NS>(ra[i][j], pc);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + r * SA + (16 * j + 4 * q) * 2) = pc[s];
+      }
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        u32x2 pc[NS];
+        sp_split4<NS>(rb[i][j], pc);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          *reinterpret_cast<u32x2*>(lds + s * PIECE + PIX * SA + r * SB + (16 * j + 4 * q) * 2) = pc[s];
+      }
+    }
+  };
+
+  f32x4 acc[TN][TK];
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k) acc[n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addresses: lane 16g+i supplies row (i>>2) of its group's 4-pixel block, columns 4(i&3)..+3
+  const int g = lane >> 4, li = lane & 15;
+  const int prow = wave * 32 + 4 * g + (li >> 2);
+  const int aoff = prow * SA + (li & 3) * 8, boff = PIX * SA + prow * SB + (li & 3) * 8;
+
+  if (nstages > 0) {
+    stage_load(0);
+    stage_store();
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) stage_load(s + 1);
+    bf16x8 bfr[TK][NS];
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) {
+        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + boff + k * 32);
+        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + boff + k * 32 + 16 * SB);
+        bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      bf16x8 afr[NS];
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) {
+        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + aoff + n * 32);
+        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + aoff + n * 32 + 16 * SA);
+        afr[pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+#pragma unroll
+      for (int k = 0; k < TK; ++k) acc[n][k] = sp_mma<NS>(afr, bfr[k], acc[n][k]);
+    }
+    __syncthreads();                       // every wave is done reading before the image is rewritten
+    if (more) stage_store();
+    __syncthreads();
+  }
+
+  // cross-wave reduction, one row of tiles at a time: red[wave][k][reg*64 + lane] (fp32)
+  float* red = reinterpret_cast<float*>(lds);
+  const int r = tid >> 6, l = tid & 63;
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(wave * TK + k) * 256 + e * 64 + lane] = acc[n][k][e];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) v += red[(wv * TK + k) * 256 + tid];
+      const int co = n0 + 16 * n + 4 * (l >> 4) + r;  // D row = 4*(lane>>4)+reg
+      const int ci = k0 + 16 * k + (l & 15);          // D col = lane&15
+      atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
+    }
+    __syncthreads();
+  }
+}
+
+template <int NS, int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_sp_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgradLds<NS, TN, TK>::BYTES];
+  const int tiles = gridDim.y, nblk = gridDim.x * gridDim.y;
+  const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
+  wgrad_sp_body<NS, TN, TK>(p, lds, r / tiles, r % tiles);
+}

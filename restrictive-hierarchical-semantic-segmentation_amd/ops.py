@@ -68,39 +68,39 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s):
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0):
     B, Hi, Wi, Cin = x_shape
     return ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
-                     Cout=Cout, ldy=ldy, ksize=k, stride=s)
+                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec)
 
 
 # ------------------------------------------------------------------ convolution
-def conv_fwd(x, w, bias, k, s, out=None, cout=None):
+def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
-    pass `cout` when w is the flat 1-D parameter slot."""
+    pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions)."""
     B, Hi, Wi, Cin = x.shape
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
-    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s)
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec)
     call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
     return out
 
 
-def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False):
+def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0):
     """wt = weight_transpose(w): [Cin][k*k][Cout]."""
     B, Hi, Wi, Cin = x_shape
     if out is None:
         out = empty_nhwc(B, Hi, Wi, Cin, dy)
         accumulate = False
-    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s)
+    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s, prec)
     call("hrseg_conv_dgrad", ptr(dy), ptr(wt), ptr(out), int(accumulate), C.byref(sh))
     return out
 
 
-def conv_wgrad(x, dy, dw, k, s):
+def conv_wgrad(x, dy, dw, k, s, prec=0):
     """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
-    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s)
+    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec)
     call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
 
 
@@ -108,35 +108,35 @@ def _shape_array(shapes):
     return (ConvShape * len(shapes))(*shapes)
 
 
-def conv_fwd_group(xs, ws, biases, k, s, couts):
+def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
     """n independent convolutions (same k, s) in one launch when the library can group them"""
     outs, shapes = [], []
     for x, co in zip(xs, couts):
         B, Hi, Wi, Cin = x.shape
         y = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), co, x)
         outs.append(y)
-        shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s))
+        shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec))
     has_bias = any(b is not None for b in biases)
     call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
          _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
     return outs
 
 
-def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate):
+def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0):
     """outs[i] None -> allocated (accumulate ignored)"""
     outs, acc, shapes = list(outs), list(accumulate), []
     for i, (dy, xs) in enumerate(zip(dys, x_shapes)):
         if outs[i] is None:
             outs[i] = empty_nhwc(xs[0], xs[1], xs[2], xs[3], dy)
             acc[i] = False
-        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s))
+        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s, prec))
     call("hrseg_conv_dgrad_group", len(dys), _lib.ptr_array(dys), _lib.ptr_array(wts), _lib.ptr_array(outs),
          _lib.int_array([int(a) for a in acc]), _shape_array(shapes))
     return outs
 
 
-def conv_wgrad_group(xs, dys, dws, k, s):
-    shapes = [_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s) for x, dy in zip(xs, dys)]
+def conv_wgrad_group(xs, dys, dws, k, s, prec=0):
+    shapes = [_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec) for x, dy in zip(xs, dys)]
     call("hrseg_conv_wgrad_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(dys), _lib.ptr_array(dws),
          _shape_array(shapes))
 
