@@ -24,6 +24,7 @@ from ..engine import Act, FlatParams, Recorder
 from ..utils.hierarchy import build_hierarchy_indices, child_groups, get_level_classes  # noqa: F401 (API)
 
 BN_MOMENTUM = 0.1
+DEFAULT_CONV_DTYPE = "f32"
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -189,6 +190,10 @@ class _EngineModel(nn.Module):
         self.dedup_passes = os.environ.get("HRSEG_DEDUP_PASSES", "0") == "1"
         # run the L training passes one after the other (as the reference does) instead of batched
         # (default per model: HRNet's many small layers gain 12 % from batching, UNet's few large ones nothing)
+        # arithmetic of the convolution contractions (include/hrseg.h hrseg_conv_precision): "f32" = exact fp32 MFMA,
+        # "bf16x3" = fp32 operands split into three bf16 pieces (fp32-grade results on the bf16 matrix pipe),
+        # "bf16x2" / "bf16" = explicit reduced-precision opt-ins (BASELINE configs[4]: bf16 inputs, fp32 accumulate)
+        self.conv_dtype = os.environ.get("HRSEG_CONV_DTYPE", DEFAULT_CONV_DTYPE)
         env = os.environ.get("HRSEG_SEQUENTIAL_PASSES")
         self.sequential_passes = (env == "1") if env is not None else not self.batch_passes_by_default
 
@@ -222,11 +227,12 @@ class _EngineModel(nn.Module):
     # -- engine forward ---------------------------------------------------------------------
     def _run(self, x, record):
         run = _Run(self)
+        prec = _lib.CONV_PRECISION[self.conv_dtype]
         self._flat.wt_stale = True          # weights may have been updated since the last call
         x_nhwc = Act(ops.nchw_to_nhwc(x.contiguous().float()), needs_grad=False)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
-            rec = Recorder(self.training, record, self._flat)
+            rec = Recorder(self.training, record, self._flat, prec=prec)
             feats = self._backbone(rec, x_nhwc)
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
@@ -257,14 +263,14 @@ class _EngineModel(nn.Module):
         for L in range(n_levels):
             if batched:
                 if shared is None:
-                    rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels)
+                    rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels, prec=prec)
                     xx = Act(x_nhwc.data.repeat(n_levels, 1, 1, 1), needs_grad=False)
                     shared, shared_rec = self._backbone(rec, xx), rec
                     run.batched_feats = shared
                 feats, rec = Act(shared.data[L * Bn:(L + 1) * Bn]), shared_rec
                 feats.slot = L               # its gradient is rows [L*B, (L+1)*B) of the stacked feature gradient
             elif shared is None:
-                rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1)
+                rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1, prec=prec)
                 feats = self._backbone(rec, x_nhwc)
                 if dedup or (not self.training and not record):
                     shared, shared_rec = feats, rec

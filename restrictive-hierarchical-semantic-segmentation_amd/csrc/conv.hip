@@ -41,6 +41,7 @@ struct IgemmArgs {
   int accumulate;            // y += result
   float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
   int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
+  int dbg;                   // timing experiments (hrseg_tune "sp_lab"): bit 0 skip weight split+store, 1 skip barrier, 2 skip fragment reads
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
 };
 
@@ -289,6 +290,7 @@ struct IgemmGroup {
   int blk_end[MAXG];
   int tiles[MAXG];   // m-tiles * n-tiles of problem g (its blocks = tiles * ksplit)
   int ksplit[MAXG];
+  int kind[MAXG];    // split-precision groups: 1 = halo-patch body (3x3 stride 1 on a wide image), 0 = im2col body
   IgemmArgs a[MAXG];
 };
 // weight-gradient problem (kernels further down)
@@ -333,6 +335,7 @@ static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
   else hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, false>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
 }
 
+static int g_sp_lab = 0;
 // tuning overrides (hrseg_tune, 0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
 static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
 
@@ -390,6 +393,7 @@ static int finalize_args(IgemmArgs& a) {
   a.rcp_hw = big ? 0.f : 1.0f / (float)(a.Ho * a.Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)a.Wo;
   a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
+  a.dbg = g_sp_lab;
   a.oy_min = a.ox_min = 0;
   for (int t = 0; t < a.ntaps; ++t) {
     const int oy = (int)((a.offy_pk >> (4 * t)) & 15) - 8, ox = (int)((a.offx_pk >> (4 * t)) & 15) - 8;
@@ -431,6 +435,57 @@ static SpPlan plan_sp(const IgemmArgs& a) {
   return pl;
 }
 
+// halo-patch body: full 3x3 stride-1 problems (forward or data gradient) on images wide enough that the
+// 8 x 16 tiles waste little and fill the chip; returns the chunks per K stage (3 or 4), 0 = not a patch case
+static int g_sp_patch = 1;              // hrseg_tune "sp_patch": 0 = never use the patch body
+// tap geometry of a full 3x3 stride-1 problem: 0 = forward (tap t reads offset (t/3-1, t%3-1)), 1 = data gradient
+// (offset (1-t/3, 1-t%3)), -1 = neither; the weight tap index must be t
+static int patch_flip(const IgemmArgs& a) {
+  if (a.ntaps != 9) return -1;
+  bool fwd = true, bwd = true;
+  for (int t = 0; t < 9; ++t) {
+    const int oy = (int)((a.offy_pk >> (4 * t)) & 15) - 8, ox = (int)((a.offx_pk >> (4 * t)) & 15) - 8;
+    if ((int)((a.wtap_pk >> (4 * t)) & 15) != t) return -1;
+    fwd = fwd && oy == t / 3 - 1 && ox == t % 3 - 1;
+    bwd = bwd && oy == 1 - t / 3 && ox == 1 - t % 3;
+  }
+  return fwd ? 0 : bwd ? 1 : -1;
+}
+static int patch_cs(const IgemmArgs& a, int wtn) {
+  if (!g_sp_patch || patch_flip(a) < 0 || a.ntaps != 9 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
+    return 0;
+  if (a.oy_min != -1 || a.ox_min != -1 || (wtn != 3 && wtn != 4 && wtn != 6)) return 0;
+  const int cs = (a.K % 48 == 0) ? 3 : (a.K % 64 == 0) ? 4 : 0;
+  if (!cs) return 0;
+  const long tiles = (long)a.B * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 16);
+  const double waste = (double)(ceil_div(a.Ho, 8) * 8) * (ceil_div(a.Wo, 16) * 16) / ((double)a.Ho * a.Wo);
+  if (waste > 1.22 || tiles * (a.N / (16 * wtn)) < 192) return 0;
+  return cs;
+}
+static long patch_tiles(const IgemmArgs& a, int wtn) {
+  return (long)a.B * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 16) * (a.N / (16 * wtn));
+}
+static int g_sp_persist = 2;            // hrseg_tune "sp_persist": persistent patch blocks per CU (0 = one tile per block)
+template <int NS>
+static int launch_patch_sp(const IgemmArgs& a, int wtn, int cs, hipStream_t st) {
+  const int ntotal = (int)patch_tiles(a, wtn);
+  int blocks = ntotal;
+  if (g_sp_persist > 0 && ntotal > 256 * g_sp_persist) {
+    // equal chunks: the block count that gives every block the same number of tiles (+-1)
+    const int per = ceil_div(ntotal, 256 * g_sp_persist);
+    blocks = ceil_div(ntotal, per);
+  }
+  const dim3 grid((unsigned)blocks);
+  const int flip = patch_flip(a);
+#define PS(N_, C_) if (wtn == N_ && cs == C_) { \
+    if (flip) hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 1>), grid, dim3(256), 0, st, a, ntotal); \
+    else hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 0>), grid, dim3(256), 0, st, a, ntotal); \
+    return 0; }
+  PS(3, 3) PS(3, 4) PS(4, 3) PS(4, 4) PS(6, 3) PS(6, 4)
+#undef PS
+  return 1;
+}
+
 template <int NS>
 static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
 #define SP2(M_, N_) \
@@ -454,6 +509,11 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
   if (int e = finalize_args(a)) return e;
   if (const int ns = sp_pieces(precision)) {
     const SpPlan pl = plan_sp(a);
+    if (const int cs = patch_cs(a, pl.wtn)) {
+      const int rc = ns == 3 ? launch_patch_sp<3>(a, pl.wtn, cs, st) : ns == 2 ? launch_patch_sp<2>(a, pl.wtn, cs, st)
+                                                                                 : launch_patch_sp<1>(a, pl.wtn, cs, st);
+      if (rc == 0) return 0;
+    }
     if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
     return ns == 3 ? launch_sp<3>(a, pl, st) : ns == 2 ? launch_sp<2>(a, pl, st) : launch_sp<1>(a, pl, st);
   }
@@ -479,10 +539,27 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
 static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
 
 template <int NS>
-static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, hipStream_t st) {
+static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, int cs, hipStream_t st) {
   bool full = true;
   for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
   const dim3 grid(g.blk_end[g.n - 1]);
+  if (cs) {      // at least one problem runs the halo-patch body (all of them with the same tap geometry)
+    int flip = -1;
+    for (int i = 0; i < g.n; ++i)
+      if (g.kind[i]) {
+        const int f = patch_flip(g.a[i]);
+        if (flip >= 0 && f != flip) return 1;
+        flip = f;
+      }
+#define SPP(M_, N_, C_) \
+    if (wtm == M_ && wtn == N_ && cs == C_) { \
+      if (flip) hipLaunchKernelGGL((igemm_sp_pgroup_kernel<NS, M_, N_, C_, 1>), grid, dim3(256), 0, st, g); \
+      else hipLaunchKernelGGL((igemm_sp_pgroup_kernel<NS, M_, N_, C_, 0>), grid, dim3(256), 0, st, g); \
+      return 0; }
+    SPP(1, 3, 3) SPP(2, 3, 3) SPP(1, 4, 4) SPP(2, 4, 4)
+#undef SPP
+    return 1;
+  }
 #define SPG(M_, N_) \
   if (wtm == M_ && wtn == N_) { \
     if (full) hipLaunchKernelGGL((igemm_sp_group_kernel<NS, M_, N_, true>), grid, dim3(256), 0, st, g); \
@@ -510,14 +587,25 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     if (a[i].N % (16 * wtn) || a[i].K % (16 * kc)) return 1;
   // per-problem split-K, then order the problems by stages per block, longest first: the blocks
   // that run longest must not be the ones dispatched last (the grid's tail)
-  int tiles[MAXG], ks[MAXG], work[MAXG], order[MAXG];
+  int tiles[MAXG], ks[MAXG], work[MAXG], order[MAXG], kind[MAXG];
   const int wtm = ns ? (g_sp_wtm ? g_sp_wtm : 2) : (g_group_wtm ? g_group_wtm : 1);
   if (ns && wtm > 2) return 1;
+  int group_cs = 0;
+  IgemmArgs fa[MAXG];
   for (int i = 0; i < n; ++i) {
-    tiles[i] = ceil_div(a[i].M, 64 * wtm) * (a[i].N / (16 * wtn));
+    fa[i] = a[i];
+    if (finalize_args(fa[i])) return 1;    // per-problem launches report the error
+    kind[i] = 0;
+    if (ns && (wtn == 3 || wtn == 4)) {
+      const int cs = patch_cs(fa[i], wtn);
+      if (cs && cs == wtn && (!group_cs || group_cs == cs)) { kind[i] = 1; group_cs = cs; }   // instances: (wtn, cs) = (3,3), (4,4)
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    tiles[i] = kind[i] ? (int)patch_tiles(fa[i], wtn) : ceil_div(a[i].M, 64 * wtm) * (a[i].N / (16 * wtn));
     const int nstages = ns ? (a[i].ntaps * (a[i].K / 16) + 1) / 2 : a[i].ntaps * (a[i].K / (16 * kc));
     ks[i] = 1;
-    const bool can_split = a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1);
+    const bool can_split = !kind[i] && (a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1));
     if (can_split && tiles[i] < 512) {
       ks[i] = ceil_div(512, tiles[i]);
       const int min_stages = ns ? 8 : 12;        // stages (fp32: 16*kc channels; split precision: 32-channel slabs) per slice
@@ -538,11 +626,11 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     g.ksplit[o] = ks[i];
     end += tiles[i] * ks[i];
     g.blk_end[o] = end;
-    g.a[o] = a[i];
-    if (finalize_args(g.a[o])) return 1;   // per-problem launches report the error
+    g.kind[o] = kind[i];
+    g.a[o] = fa[i];
   }
-  if (ns) return ns == 3 ? launch_sp_group<3>(g, wtm, wtn, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, st)
-                                                                            : launch_sp_group<1>(g, wtm, wtn, st);
+  if (ns) return ns == 3 ? launch_sp_group<3>(g, wtm, wtn, group_cs, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, group_cs, st)
+                                                                                      : launch_sp_group<1>(g, wtm, wtn, group_cs, st);
   if (wtm == 2 && wtn == 3 && kc == 3) launch_igemm_group<2, 3, 3, 1>(g, st);
   else if (wtm == 2 && wtn == 3) launch_igemm_group<2, 3, 1, 1>(g, st);
   else if (wtm == 2) return 1;
@@ -1307,7 +1395,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}};
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_lab", &g_sp_lab}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.v = value; return 0; }

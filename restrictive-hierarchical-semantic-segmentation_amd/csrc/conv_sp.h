@@ -472,3 +472,272 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(WgradArgs p) {
   const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
   wgrad_sp_body<NS, TN, TK>(p, lds, r / tiles, r % tiles);
 }
+
+// --------------------------------------------------------------------------- 3x3 stride-1: halo patch in LDS
+// At bf16 matrix rates the im2col body above is bound by the L2 -> CU path: every input pixel is pulled nine
+// times (once per tap) for only 16*WTN output channels (measured: ~8 TB/s of operand traffic whatever the
+// number of products).  For 3x3 stride-1 convolutions (forward and data gradient) this body stages the
+// (TH+2) x 18 input patch of a TH x 16 output tile ONCE per K stage, already split into bf16 pieces (one split
+// per element instead of nine), and the nine taps read their pixel fragments from LDS at shifted positions.
+//   patch image : [piece][16-channel chunk][patch pixel][32 B]; the four 8-byte granules of a row are XOR-ed
+//                 with 2*((pixel>>3)&1): 16 consecutive pixels x 2 granules = one conflict-free ds_read_b64
+//   reduction   : units (tap, chunk) of the K stage, flattened; a slab = two consecutive units (so 48-channel
+//                 stages pair chunk 2 of one tap with chunk 0 of the next); weight slabs stream through a
+//                 double-buffered LDS image as in igemm_sp_body
+//   wave w owns tile rows [w*RPW, (w+1)*RPW), all 16 columns, all 16*WTN channels.
+template <int NS, int TH, int WTN, int CS>
+struct SpPatchLds {
+  static constexpr int PP = (TH + 2) * 18;              // patch pixels
+  static constexpr int CHUNK = PP * 32;                 // bytes per chunk image
+  static constexpr int PPIECE = CS * CHUNK;             // per piece
+  static constexpr int PATCH = NS * PPIECE;
+  static constexpr int WPIECE = 16 * WTN * 64, WSTAGE = NS * WPIECE;
+  static constexpr int BYTES = PATCH + 3 * WSTAGE;      // weight slabs: three buffers (fragments are read one slab ahead)
+};
+
+// Work list of a block: output tiles first, first + stride, ... (< end), each with K / (16*CS) K stages.  The
+// slab loop of a K stage is fully unrolled (tap offsets, chunk indices and register-set parity are compile-time
+// constants; FLIP selects the data-gradient tap geometry), so a slab costs its LDS reads, its MFMAs, one
+// weight-slab load + split + store and ONE barrier.  Software pipeline per slab:
+//   top    : weight + pixel FRAGMENTS of slab s+1 are read from LDS into the second register set; global
+//            loads of the weight slab s+2 are issued (and, two slabs before a K stage ends, of the next
+//            patch: next K stage of this tile or first K stage of the block's next tile)
+//   middle : the MFMAs of slab s on the register set filled during slab s-1 -- they wait for nothing
+//   bottom : weight slab s+2 is split and stored into the third LDS buffer; at a K-stage boundary the next
+//            patch replaces the current one (its last fragments were read a slab, i.e. a barrier, earlier)
+template <int NS, int TH, int WTN, int CS, int FLIP>
+__device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned char* lds, const int first, const int stride,
+                                                    const int end) {
+  using L = SpPatchLds<NS, TH, WTN, CS>;
+  constexpr int RPW = TH / 4, BN = 16 * WTN, PW = 18, PP = L::PP;
+  constexpr int PG = PP * CS * 4;                          // 16-byte granules of one K stage of the patch
+  constexpr int P_LOADS = (PG + 255) / 256;
+  constexpr int WG = BN * 8, W_LOADS = (WG + 255) / 256;
+  constexpr int NU = 9 * CS, NSLAB = (NU + 1) / 2;         // units / slabs per K stage
+  static_assert(NSLAB % 2 == 0, "register-set parity must restart with every K stage");
+  static_assert(WG >= 256 && PG >= 256, "the spare lanes of a partial round repeat a granule of the round before");
+  unsigned char* lpatch = lds;
+  unsigned char* lw = lds + L::PATCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int H = p.Ho, W = p.Wo;                            // stride 1, pad 1: input and output are H x W
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
+  const int ntn = p.N / BN;
+  const int nks = p.K / (16 * CS);
+  if (first >= end) return;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (size_t)p.N * p.T * p.K * 4);
+
+  struct Geom { int b, y0, x0, n0; };
+  auto tile_geom = [&](int t) {       // channel tile fastest, then tile column, tile row, image
+    Geom q;
+    const int nt = t % ntn;
+    int mt = t / ntn;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    q.b = mt / tiles_y;
+    q.y0 = ty * TH; q.x0 = tx * 16; q.n0 = nt * BN;
+    return q;
+  };
+
+  // patch granules of this thread: f = tid + 256 i -> (patch pixel, chunk, 4-channel group)
+  f32x4 rp[P_LOADS];
+  auto patch_load = [&](const Geom& q, int ks) {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)q.b * H * W * p.ldx, (size_t)H * W * p.ldx * 4);
+#pragma unroll
+    for (int i = 0; i < P_LOADS; ++i) {
+      int f = tid + 256 * i;
+      if (f >= PG) f -= 256;          // the spare lanes of the last round repeat a granule of the round before (no branch)
+      const int pix = f / (CS * 4), rem = f - pix * (CS * 4);
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = q.y0 - 1 + py, ix = q.x0 - 1 + px;
+      const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+      const unsigned off = ok ? (unsigned)(iy * W + ix) * (unsigned)(p.ldx * 4) + (unsigned)(rem * 16) : HRSEG_BUF_OOB;
+      rp[i] = buf_load4(rx, off, ks * CS * 64);
+    }
+  };
+  auto patch_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_LOADS; ++i) {
+      u32x2 pc[NS];
+      sp_split4<NS>(rp[i], pc);
+      int f = tid + 256 * i;
+      if (f >= PG) f -= 256;
+      const int pix = f / (CS * 4), rem = f - pix * (CS * 4);
+      const int c = rem >> 2, q = rem & 3;
+      const int o = c * L::CHUNK + pix * 32 + ((q ^ (2 * ((pix >> 3) & 1))) << 3);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
+    }
+  };
+
+  // weight granules: f -> (row n = f>>3, unit (f>>2)&1, 4-channel group f&3), as in igemm_sp_body
+  unsigned wrow[W_LOADS];
+  int wst[W_LOADS];
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    int f = tid + 256 * i;
+    if (f >= WG) f -= 256;            // spare lanes repeat a granule of the round before: same data to the same slot
+    const int n = f >> 3, unit = (f >> 2) & 1, gq = f & 3;
+    wrow[i] = ((unsigned)n * (unsigned)(p.T * p.K) + 4u * gq) * 4u;
+    wst[i] = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
+  }
+  const bool wunit1 = (tid >> 2) & 1;        // (f>>2)&1 is the same for every i (256 is a multiple of 8)
+  f32x4 rwt[2][W_LOADS];        // two slabs in flight: loaded a slab before they are split and stored
+  // weight slab `slab` (compile-time after unrolling) of K stage ks for channel tile n0 -> register set `set`
+  auto w_load = [&](int n0, int ks, int slab, int set) {
+    const int uA = 2 * slab, uB = 2 * slab + 1;
+    const int tA = uA / CS, cA = uA - tA * CS, tB = uB / CS, cB = uB - tB * CS;      // weight tap index = tap
+    const unsigned col0 = (unsigned)(n0 * p.T * p.K + ks * CS * 16) * 4u;
+    const unsigned sA = col0 + (unsigned)(tA * p.K + cA * 16) * 4u;
+    const unsigned sB = (uB < NU) ? col0 + (unsigned)(tB * p.K + cB * 16) * 4u : HRSEG_BUF_OOB;
+    const unsigned so = wunit1 ? sB : sA;
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const unsigned off = (so == HRSEG_BUF_OOB) ? HRSEG_BUF_OOB : wrow[i] + so;
+      rwt[set][i] = buf_load4(rw, off, 0);
+    }
+  };
+  auto w_store = [&](int wboff, int set) {
+    unsigned char* base = lw + wboff;
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      u32x2 pc[NS];
+      sp_split4<NS>(rwt[set][i], pc);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(base + s * L::WPIECE + wst[i]) = pc[s];
+    }
+  };
+
+  const int foff = r16 * 64 + lds_slot(r16, g) * 16;       // weight fragment inside a 16-row tile
+  const int prow0 = (wave * RPW) * PW + r16;               // patch pixel of (tile row wave*RPW, column r16) at tap offset (0,0)
+  // this lane's pixel-fragment byte offsets for patch pixels prow0 + d: the granule swizzle depends on bit 3 of
+  // the pixel index, so keep both variants of (pixel*32 + granule*8) and pick per (compile-time) offset d
+  const int pbase = prow0 * 32;
+
+  // fragments of slab `slab` (compile-time) from the current patch and weight buffer offset wboff
+  auto read_frags = [&](int slab, int wboff, bf16x8 (&xf)[RPW][NS], bf16x8 (&wf)[WTN][NS]) {
+    const int uA = 2 * slab, uB = 2 * slab + 1;
+    const int tA = uA / CS, cA = uA - tA * CS;
+    const int tB = (uB < NU) ? uB / CS : 0, cB = (uB < NU) ? uB - tB * CS : 0;
+    const int dA = (FLIP ? 2 - tA / 3 : tA / 3) * PW + (FLIP ? 2 - tA % 3 : tA % 3);
+    const int dB = (FLIP ? 2 - tB / 3 : tB / 3) * PW + (FLIP ? 2 - tB % 3 : tB % 3);
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) {
+      const int pa = prow0 + m * PW + dA, pb = prow0 + m * PW + dB;
+      const int oa = cA * L::CHUNK + pbase + (m * PW + dA) * 32 + ((g ^ (2 * ((pa >> 3) & 1))) << 3);
+      const int ob = cB * L::CHUNK + pbase + (m * PW + dB) * 32 + ((g ^ (2 * ((pb >> 3) & 1))) << 3);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(lpatch + q * L::PPIECE + oa);
+        u32x2 hi = u32x2{0u, 0u};
+        if (uB < NU) hi = *reinterpret_cast<const u32x2*>(lpatch + q * L::PPIECE + ob);
+        xf[m][q] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+      }
+    }
+    const unsigned char* base = lw + wboff;
+#pragma unroll
+    for (int n = 0; n < WTN; ++n)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) wf[n][q] = *reinterpret_cast<const bf16x8*>(base + q * L::WPIECE + n * 1024 + foff);
+  };
+
+  f32x4 acc[WTN][RPW];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int n = 0; n < WTN; ++n)
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_tile = [&](const Geom& q) {
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) {
+      const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+      if (oy >= H || ox >= W) continue;
+      float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) {
+        const int ch = q.n0 + 16 * n + 4 * g;
+        f32x4 v = acc[n][m];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        *reinterpret_cast<f32x4*>(yrow + ch) = v;
+      }
+    }
+  };
+
+  bf16x8 xfr[2][RPW][NS], wfr[2][WTN][NS];
+  int t = first;
+  Geom cur = tile_geom(t);
+  // prologue: patch of the first K stage, weight slabs 0 and 1, fragments of slab 0
+  patch_load(cur, 0);
+  w_load(cur.n0, 0, 0, 0);
+  w_load(cur.n0, 0, 1, 1);
+  patch_store();
+  w_store(0, 0);
+  w_store(L::WSTAGE, 1);
+  w_load(cur.n0, 0, 2, 0);           // stored by the first slab of the loop
+  __syncthreads();
+  read_frags(0, 0, xfr[0], wfr[0]);
+  zero_acc();
+  int wb = 0;                        // byte offset of the CURRENT slab's weight buffer (three buffers, rotating)
+  for (;;) {
+    bool have_next = false;
+    for (int ks = 0; ks < nks; ++ks) {
+      const bool last_ks = ks + 1 == nks;
+      const int nt = last_ks ? t + stride : t;
+      const int nks_ = last_ks ? 0 : ks + 1;
+      have_next = nt < end;
+      Geom nxt = cur;
+      if (last_ks && have_next) nxt = tile_geom(nt);
+#pragma unroll
+      for (int s = 0; s < NSLAB; ++s) {
+        const int wb1 = (wb == 2 * L::WSTAGE) ? 0 : wb + L::WSTAGE;
+        const int wb2 = (wb1 == 2 * L::WSTAGE) ? 0 : wb1 + L::WSTAGE;
+        // weight slab s+3 -> registers (split + stored a slab later); s+2 is in the other register set
+        if (s + 3 < NSLAB) w_load(cur.n0, ks, s + 3, (s + 1) & 1);
+        else if (have_next) w_load(nxt.n0, nks_, s + 3 - NSLAB, (s + 1) & 1);
+        if (s == NSLAB - 3 && have_next) patch_load(nxt, nks_);          // in flight behind three slabs of MFMAs
+        if (s + 1 < NSLAB && !(p.dbg & 4)) read_frags(s + 1, wb1, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
+#pragma unroll
+        for (int n = 0; n < WTN; ++n)
+#pragma unroll
+          for (int m = 0; m < RPW; ++m) acc[n][m] = sp_mma<NS>(wfr[s & 1][n], xfr[s & 1][m], acc[n][m]);
+        if ((s + 2 < NSLAB || have_next) && !(p.dbg & 1)) w_store(wb2, s & 1);
+        if (s == NSLAB - 1) {
+          if (last_ks) { store_tile(cur); zero_acc(); }
+          if (have_next) patch_store();
+        }
+        if (!(p.dbg & 2)) __syncthreads();
+        if (s == NSLAB - 1 && have_next) read_frags(0, wb1, xfr[0], wfr[0]);  // first slab of the new patch
+        wb = wb1;
+      }
+      if (last_ks) cur = nxt;
+    }
+    if (!have_next) break;
+    t += stride;
+  }
+}
+
+template <int NS, int TH, int WTN, int CS, int FLIP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_patch_sp_kernel(IgemmArgs p, int ntotal) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchLds<NS, TH, WTN, CS>::BYTES];
+  // a block owns `chunk` consecutive tiles (neighbours in x share halo columns: L2 hits in time)
+  const int chunk = (ntotal + gridDim.x - 1) / gridDim.x;
+  const int first = blockIdx.x * chunk;
+  igemm_patch_sp_body<NS, TH, WTN, CS, FLIP>(p, lds, first, 1, min(first + chunk, ntotal));
+}
+
+// grouped launch whose problems run either body (the parallel HRNet branches: the wide high-resolution
+// branches take the halo-patch body, the small low-resolution ones the im2col body with split-K)
+template <int NS, int WTM, int WTN, int CS, int FLIP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_sp_pgroup_kernel(IgemmGroup grp) {
+  constexpr int A = SpPatchLds<NS, 8, WTN, CS>::BYTES, B = SpLds<NS, WTN>::BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A > B ? A : B];
+  int gi = 0;
+  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
+  const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
+  const int tiles = grp.tiles[gi];
+  if (grp.kind[gi]) igemm_patch_sp_body<NS, 8, WTN, CS, FLIP>(grp.a[gi], lds, local, 1 << 29, tiles);   // one tile per block
+  else igemm_sp_body<NS, WTM, WTN>(grp.a[gi], lds, local % tiles, tiles, local / tiles, grp.ksplit[gi]);
+}

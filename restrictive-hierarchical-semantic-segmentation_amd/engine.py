@@ -158,7 +158,8 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1):
+    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0):
+        self.prec = prec                 # _lib.CONV_PRECISION code of every convolution of this forward (and its backward)
         self.training = training
         self.record = record
         self.bn_repeat = bn_repeat       # running-stat updates per BN (level passes run as one)
@@ -221,11 +222,11 @@ class Recorder:
         if n == 1:
             conv = items[0][1]
             ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
-                               k, s, cout=conv.out_channels)]
+                               k, s, cout=conv.out_channels, prec=self.prec)]
         else:
             ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
                                     [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
-                                    [c.out_channels for _, c, _, _ in items])
+                                    [c.out_channels for _, c, _, _ in items], prec=self.prec)
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
                          residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
@@ -261,9 +262,10 @@ class Recorder:
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 if n == 1:
-                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s)
+                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec)
                 else:
-                    ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s)
+                    ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
+                                         prec=self.prec)
             if side is not None:
                 for t in dys:
                     t.record_stream(side)     # not reused before the side stream is done reading it
@@ -281,13 +283,14 @@ class Recorder:
                     i = rnd[0]
                     x = xs[i]
                     if x.grad is None:
-                        x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s)
+                        x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, prec=self.prec)
                     else:
-                        ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, out=x.grad, accumulate=True)
+                        ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, out=x.grad, accumulate=True,
+                                       prec=self.prec)
                 else:
                     got = ops.conv_dgrad_group([dys[i] for i in rnd], [self._wt(items[i][1]) for i in rnd],
                                                [xs[i].data.shape for i in rnd], k, s, [xs[i].grad for i in rnd],
-                                               [xs[i].grad is not None for i in rnd])
+                                               [xs[i].grad is not None for i in rnd], prec=self.prec)
                     for i, o in zip(rnd, got):
                         xs[i].grad = o
                 todo = rest
