@@ -57,8 +57,10 @@ int hrseg_abi_version(void);
  *           v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-grade (dropped terms < 2^-24 relative)
  *           at 16/6 of the fp32 matrix rate
  *   BF16X2  2 pieces, 3 products (operand error 2^-16)
- *   BF16    operands rounded to bf16, fp32 accumulation (BASELINE configs[4] arithmetic)              */
-enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3 };
+ *   BF16    operands rounded to bf16, fp32 accumulation (BASELINE configs[4] arithmetic)
+ *   AUTO    fp32-grade results from the faster family per problem: BF16X3 for forward / data-gradient
+ *           problems of at least 8192 output pixels, F32 for small ones and for weight gradients         */
+enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3, HRSEG_CONV_AUTO = 4 };
 typedef struct {
   int B, Hi, Wi, Cin, ldx; /* input  x[B,Hi,Wi,Cin], row stride ldx   */
   int Ho, Wo, Cout, ldy;   /* output y[B,Ho,Wo,Cout], row stride ldy  */
@@ -95,6 +97,15 @@ int hrseg_conv_dgrad_group(int n, const float* const* dy, const float* const* wt
                            hrseg_stream_t stream);
 int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy, float* const* dw,
                            const hrseg_conv_shape_t* shapes, hrseg_stream_t stream);
+/* Weight gradients with a caller-provided workspace: full 3x3 stride-1 problems in a split-precision mode
+ * (channels multiples of 48, or of 64) run the nine-tap kernel -- per-block partial sums written with plain
+ * stores into the workspace, then added to dw in a fixed order (no atomics: bit-reproducible).
+ * hrseg_conv_wgrad_workspace_bytes returns the size that path needs for the n problems (0: it does not
+ * apply); with a NULL / too small workspace, or other shapes, the call is hrseg_conv_wgrad_group. */
+size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes);
+int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
+                              const hrseg_conv_shape_t* shapes, void* workspace, size_t workspace_bytes,
+                              hrseg_stream_t stream);
 /* tile-plan overrides for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
  * wgrad_group_min, wgrad_group_max (csrc/conv.hip, hrseg_tune).  Unknown key: HRSEG_ERR_INVALID_ARG. */

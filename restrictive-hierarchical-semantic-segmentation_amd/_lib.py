@@ -35,7 +35,7 @@ class ConvShape(C.Structure):
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
-CONV_PRECISION = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "bf16": 3}
+CONV_PRECISION = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "bf16": 3, "auto": 4}
 
 
 class BnFwd(C.Structure):
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "hrseg_conv_fwd_group": [_i, _p, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_conv_dgrad_group": [_i, _p, _p, _p, _p, C.POINTER(ConvShape), _p],
     "hrseg_conv_wgrad_group": [_i, _p, _p, _p, C.POINTER(ConvShape), _p],
+    "hrseg_conv_wgrad_group_ws": [_i, _p, _p, _p, C.POINTER(ConvShape), _p, C.c_size_t, _p],
     "hrseg_weight_transpose": [_p, _p, _i, _i, _i, _p],
     "hrseg_weight_transpose_all": [_p, _p, _p, _i, _p],
     "hrseg_bn_stats": [_p, _i, _l, _i, _p, _i, _p],
@@ -115,6 +116,15 @@ _lib.hrseg_last_error_string.restype = C.c_char_p
 _lib.hrseg_last_error_string.argtypes = []
 _lib.hrseg_abi_version.restype = _i
 _lib.hrseg_abi_version.argtypes = []
+
+_lib.hrseg_conv_wgrad_workspace_bytes.restype = C.c_size_t
+_lib.hrseg_conv_wgrad_workspace_bytes.argtypes = [_i, C.POINTER(ConvShape)]
+
+
+def conv_wgrad_workspace_bytes(shapes):
+    """bytes of workspace the nine-tap weight-gradient path wants for these problems (0: not applicable)"""
+    return int(_lib.hrseg_conv_wgrad_workspace_bytes(len(shapes), shapes))
+
 
 _lib.hrseg_tune.restype = _i
 _lib.hrseg_tune.argtypes = [C.c_char_p, _i]

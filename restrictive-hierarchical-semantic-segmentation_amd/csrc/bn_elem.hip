@@ -625,22 +625,39 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
       sc = ld4(coef + 2 * C + 4 * L.cq);
       sh = ld4(coef + 3 * C + 4 * L.cq);
     }
-    for (long pix = lo + L.pl; pix < hi; pix += L.P) {
-      f32x4 v = ld4(a0 + pix * ld0 + 4 * L.cq);
-      if (!bwd) {
-        s += v;
-        s2 += v * v;
-      } else {
-        const f32x4 yv = ld4(yy + pix * ldy + 4 * L.cq);
-        if (relu) {
-          // z not given: the forward had no residual, so z > 0 <=> y*scale+shift > 0 (4 bytes less per element)
-          const f32x4 zz = zmask ? ld4(zmask + pix * ldz + 4 * L.cq) : bn_affine(yv, sc, sh);
+    // four pixels per trip, all loads issued before the first use: a chunk is walked by few threads, so the
+    // bytes in flight per CU (what HBM-bound code lives on) come from this unrolling
+    constexpr int U = 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long pix0 = lo + L.pl; pix0 < hi; pix0 += (long)U * L.P) {
+      f32x4 v[U], yv[U], zz[U];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = zz[j] > 0.f ? v[j] : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const long pix = pix0 + (long)u * L.P;
+        const bool ok = pix < hi;
+        v[u] = ok ? ld4(a0 + pix * ld0 + 4 * L.cq) : zero;
+        if (bwd) {
+          yv[u] = ok ? ld4(yy + pix * ldy + 4 * L.cq) : mean;
+          if (relu && zmask) zz[u] = ok ? ld4(zmask + pix * ldz + 4 * L.cq) : zero;
         }
-        const f32x4 xh = (yv - mean) * rstd;
-        s += v;
-        s2 += v * xh;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!bwd) {
+          s += v[u];
+          s2 += v[u] * v[u];
+        } else {
+          f32x4 gv = v[u];
+          if (relu) {
+            // z not given: the forward had no residual, so z > 0 <=> y*scale+shift > 0 (4 bytes less per element)
+            const f32x4 zc = zmask ? zz[u] : bn_affine(yv[u], sc, sh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = zc[j] > 0.f ? gv[j] : 0.f;
+          }
+          const f32x4 xh = (yv[u] - mean) * rstd;
+          s += gv;
+          s2 += gv * xh;
+        }
       }
     }
   }

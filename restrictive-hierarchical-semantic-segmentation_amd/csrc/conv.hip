@@ -41,7 +41,6 @@ struct IgemmArgs {
   int accumulate;            // y += result
   float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
   int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
-  int dbg;                   // timing experiments (hrseg_tune "sp_lab"): bit 0 skip weight split+store, 1 skip barrier, 2 skip fragment reads
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
 };
 
@@ -335,7 +334,6 @@ static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
   else hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, false>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
 }
 
-static int g_sp_lab = 0;
 // tuning overrides (hrseg_tune, 0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
 static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
 
@@ -393,7 +391,6 @@ static int finalize_args(IgemmArgs& a) {
   a.rcp_hw = big ? 0.f : 1.0f / (float)(a.Ho * a.Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)a.Wo;
   a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
-  a.dbg = g_sp_lab;
   a.oy_min = a.ox_min = 0;
   for (int t = 0; t < a.ntaps; ++t) {
     const int oy = (int)((a.offy_pk >> (4 * t)) & 15) - 8, ox = (int)((a.offx_pk >> (4 * t)) & 15) - 8;
@@ -504,9 +501,18 @@ static int sp_pieces(int precision) {    // hrseg_conv_precision -> bf16 pieces 
   return precision == HRSEG_CONV_BF16X3 ? 3 : precision == HRSEG_CONV_BF16X2 ? 2 : precision == HRSEG_CONV_BF16 ? 1 : 0;
 }
 
+// HRSEG_CONV_AUTO: fp32-grade results from whichever kernel family is faster for the problem (measured on
+// MI355X, tools/sp_bench.py): the bf16x3 kernels for problems of at least 8192 output pixels (the halo-patch
+// body on wide 3x3 stride-1 images, the im2col body otherwise), the fp32 MFMA kernels for the small ones
+static int resolve_auto(const IgemmArgs& a, int precision) {
+  if (precision != HRSEG_CONV_AUTO) return precision;
+  return a.M >= 8192 ? HRSEG_CONV_BF16X3 : HRSEG_CONV_F32;
+}
+
 static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
   IgemmArgs a = a_in;
   if (int e = finalize_args(a)) return e;
+  precision = resolve_auto(a, precision);
   if (const int ns = sp_pieces(precision)) {
     const SpPlan pl = plan_sp(a);
     if (const int cs = patch_cs(a, pl.wtn)) {
@@ -570,8 +576,34 @@ static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, int cs, hipStr
   return 1;
 }
 
+static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st);
+// HRSEG_CONV_AUTO on a group: the problems the halo-patch body takes go out as one bf16x3 launch, the rest as
+// one fp32 launch (a low-resolution branch inside a patch launch would run at the patch body's occupancy)
+static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st) {
+  IgemmArgs hi[MAXG], lo[MAXG];
+  int nh = 0, nl = 0;
+  for (int i = 0; i < n; ++i) {
+    IgemmArgs f = a[i];
+    if (finalize_args(f)) return 1;
+    const int wtn = (f.N % 48 == 0) ? 3 : (f.N % 64 == 0) ? 4 : 0;
+    if (wtn && patch_cs(f, wtn) == wtn) hi[nh++] = a[i];
+    else lo[nl++] = a[i];
+  }
+  if (nh == 0) return dispatch_igemm_group(a, n, HRSEG_CONV_F32, st);
+  int rc = (nh >= 2) ? dispatch_igemm_group(hi, nh, HRSEG_CONV_BF16X3, st) : 1;
+  if (rc != 0)
+    for (int i = 0; i < nh; ++i)
+      if (int e = dispatch_igemm(hi[i], HRSEG_CONV_BF16X3, st)) return e < 0 ? e : 1;
+  rc = (nl >= 2) ? dispatch_igemm_group(lo, nl, HRSEG_CONV_F32, st) : 1;
+  if (rc != 0)
+    for (int i = 0; i < nl; ++i)
+      if (int e = dispatch_igemm(lo[i], HRSEG_CONV_AUTO, st)) return e < 0 ? e : 1;
+  return 0;
+}
+
 static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
+  if (precision == HRSEG_CONV_AUTO) return dispatch_igemm_group_auto(a, n, st);
   const int ns = sp_pieces(precision);
   int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
   const int kc = ns ? 1 : (a[0].K % 48 == 0) ? 3 : (a[0].K % 32 == 0) ? 2 : 1;
@@ -1052,6 +1084,73 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
   return 0;
 }
 
+// --------------------------------------------------------------------------- nine-tap weight gradient (workspace + ordered reduce)
+static int g_wg9_blocks = 0;           // hrseg_tune "wgrad9_blocks": target blocks per problem (0 = 256)
+static int g_wg9 = 1;                  // hrseg_tune "wgrad9": 0 = never use the nine-tap kernel
+// tiles per side of the dW tile (3: channels multiple of 48, 4: multiple of 64), 0 = not a nine-tap case
+static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
+  if (!g_wg9 || s.ksize != 3 || s.stride != 1 || sp_pieces(s.precision) == 0) return 0;
+  if (s.Cin % 48 == 0 && s.Cout % 48 == 0) return 3;
+  if (s.Cin % 64 == 0 && s.Cout % 64 == 0) return 4;
+  return 0;
+}
+static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a) {
+  a.B = s.B; a.H = s.Hi; a.W = s.Wi; a.Cin = s.Cin; a.Cout = s.Cout; a.ldx = s.ldx; a.lddy = s.ldy;
+  a.tiles_x = ceil_div(s.Wi, 16); a.tiles_y = ceil_div(s.Hi, 4);
+  a.ntiles = s.B * a.tiles_x * a.tiles_y;
+  const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
+  int chunks = ceil_div(g_wg9_blocks ? g_wg9_blocks : 256, npairs);
+  if (chunks > a.ntiles) chunks = a.ntiles;
+  if (chunks < 1) chunks = 1;
+  a.per = ceil_div(a.ntiles, chunks);
+  a.nchunks = ceil_div(a.ntiles, a.per);
+}
+// bytes of workspace the nine-tap path wants for these problems (0: not applicable to all of them)
+static size_t wgrad9_ws_bytes(int n, const hrseg_conv_shape_t* shapes) {
+  if (n < 1 || n > WG9_MAXG) return 0;
+  const int tnk = wgrad9_tnk(shapes[0]);
+  if (!tnk) return 0;
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (wgrad9_tnk(shapes[i]) != tnk || shapes[i].precision != shapes[0].precision) return 0;
+    Wgrad9Args a;
+    wgrad9_plan(shapes[i], tnk, a);
+    total += (size_t)a.nchunks * shapes[i].Cout * 9 * shapes[i].Cin * 4;
+  }
+  return total;
+}
+static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy, float* const* dw,
+                           const hrseg_conv_shape_t* shapes, float* ws, hipStream_t st) {
+  const int tnk = wgrad9_tnk(shapes[0]), ns = sp_pieces(shapes[0].precision);
+  Wgrad9Group g;
+  Wgrad9Reduce r;
+  g.n = r.n = n;
+  int end = 0, rend = 0;
+  for (int i = 0; i < n; ++i) {
+    Wgrad9Args& a = g.a[i];
+    wgrad9_plan(shapes[i], tnk, a);
+    a.x = x[i]; a.dy = dy[i]; a.ws = ws;
+    HRSEG_CHECK_ARG((double)shapes[i].Hi * shapes[i].Wi * (double)(shapes[i].ldx > shapes[i].ldy ? shapes[i].ldx : shapes[i].ldy) * 4.0 < 4294967296.0,
+                    "wgrad9: one image exceeds the 4 GB buffer-offset range");
+    const long elems = (long)shapes[i].Cout * 9 * shapes[i].Cin;
+    end += (shapes[i].Cout / (16 * tnk)) * (shapes[i].Cin / (16 * tnk)) * a.nchunks;
+    g.blk_end[i] = end;
+    r.ws[i] = ws; r.dw[i] = dw[i]; r.nchunks[i] = a.nchunks; r.n4[i] = elems / 4;
+    rend += (int)((elems / 4 + 31) / 32 < 2048 ? (elems / 4 + 31) / 32 : 2048);
+    r.blk_end[i] = rend;
+    ws += (size_t)a.nchunks * elems;
+  }
+#define W9(NS_) if (ns == NS_) { \
+    if (tnk == 3) hipLaunchKernelGGL((wgrad9_sp_group_kernel3<NS_>), dim3(end), dim3(192), 0, st, g); \
+    else hipLaunchKernelGGL((wgrad9_sp_group_kernel4<NS_>), dim3(end), dim3(192), 0, st, g); }
+  W9(1) W9(2) W9(3)
+#undef W9
+  HRSEG_LAUNCH_CHECK("wgrad9");
+  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rend), dim3(256), 0, st, r);
+  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+  return 0;
+}
+
 // --------------------------------------------------------------------------- weight transpose
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int T,
                                         int Cin) {
@@ -1094,7 +1193,7 @@ __global__ void weight_transpose_all_kernel(const float* __restrict__ flat, floa
 static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(s != nullptr, "%s: null shape", who);
   HRSEG_CHECK_ARG(s->ksize == 1 || s->ksize == 3, "%s: ksize %d not in {1,3}", who, s->ksize);
-  HRSEG_CHECK_ARG(s->precision >= HRSEG_CONV_F32 && s->precision <= HRSEG_CONV_BF16, "%s: precision %d is not a hrseg_conv_precision",
+  HRSEG_CHECK_ARG(s->precision >= HRSEG_CONV_F32 && s->precision <= HRSEG_CONV_AUTO, "%s: precision %d is not a hrseg_conv_precision",
                   who, s->precision);
   HRSEG_CHECK_ARG(s->stride == 1 || s->stride == 2, "%s: stride %d not in {1,2}", who, s->stride);
   HRSEG_CHECK_ARG(s->B > 0 && s->Hi > 0 && s->Wi > 0 && s->Cin > 0 && s->Cout > 0, "%s: non-positive dims", who);
@@ -1229,6 +1328,27 @@ extern "C" int hrseg_conv_wgrad_group(int n, const float* const* x, const float*
   for (int i = 0; i < n; ++i)
     if (int e = hrseg_conv_wgrad(x[i], dy[i], dw[i], &shapes[i], stream)) return e;
   return 0;
+}
+
+extern "C" size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes) {
+  if (!shapes) return 0;
+  for (int i = 0; i < n; ++i)
+    if (check_shape(&shapes[i], "hrseg_conv_wgrad_workspace_bytes")) return 0;
+  return wgrad9_ws_bytes(n, shapes);
+}
+
+extern "C" int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
+                                         const hrseg_conv_shape_t* shapes, void* workspace, size_t workspace_bytes,
+                                         hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(n >= 1 && x && dy && dw && shapes, "hrseg_conv_wgrad_group_ws: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (int e = check_shape(&shapes[i], "hrseg_conv_wgrad_group_ws")) return e;
+  const size_t need = wgrad9_ws_bytes(n, shapes);
+  if (need && workspace && workspace_bytes >= need) {
+    for (int i = 0; i < n; ++i) HRSEG_CHECK_ARG(x[i] && dy[i] && dw[i], "hrseg_conv_wgrad_group_ws: null pointer");
+    return dispatch_wgrad9(n, x, dy, dw, shapes, (float*)workspace, (hipStream_t)stream);
+  }
+  return hrseg_conv_wgrad_group(n, x, dy, dw, shapes, stream);
 }
 
 extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -1395,7 +1515,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_lab", &g_sp_lab}};
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.v = value; return 0; }

@@ -698,17 +698,17 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
         if (s + 3 < NSLAB) w_load(cur.n0, ks, s + 3, (s + 1) & 1);
         else if (have_next) w_load(nxt.n0, nks_, s + 3 - NSLAB, (s + 1) & 1);
         if (s == NSLAB - 3 && have_next) patch_load(nxt, nks_);          // in flight behind three slabs of MFMAs
-        if (s + 1 < NSLAB && !(p.dbg & 4)) read_frags(s + 1, wb1, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
+        if (s + 1 < NSLAB) read_frags(s + 1, wb1, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
 #pragma unroll
         for (int n = 0; n < WTN; ++n)
 #pragma unroll
           for (int m = 0; m < RPW; ++m) acc[n][m] = sp_mma<NS>(wfr[s & 1][n], xfr[s & 1][m], acc[n][m]);
-        if ((s + 2 < NSLAB || have_next) && !(p.dbg & 1)) w_store(wb2, s & 1);
+        if (s + 2 < NSLAB || have_next) w_store(wb2, s & 1);
         if (s == NSLAB - 1) {
           if (last_ks) { store_tile(cur); zero_acc(); }
           if (have_next) patch_store();
         }
-        if (!(p.dbg & 2)) __syncthreads();
+        __syncthreads();
         if (s == NSLAB - 1 && have_next) read_frags(0, wb1, xfr[0], wfr[0]);  // first slab of the new patch
         wb = wb1;
       }
@@ -740,4 +740,211 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tiles = grp.tiles[gi];
   if (grp.kind[gi]) igemm_patch_sp_body<NS, 8, WTN, CS, FLIP>(grp.a[gi], lds, local, 1 << 29, tiles);   // one tile per block
   else igemm_sp_body<NS, WTM, WTN>(grp.a[gi], lds, local % tiles, tiles, local / tiles, grp.ksplit[gi]);
+}
+
+// --------------------------------------------------------------------------- weight gradient, 3x3 stride 1: all nine taps per block
+// The tap-per-block weight gradient above pulls dy and x through L2 nine times and splits every element nine
+// times.  Here a block owns a (16*TNK couts) x (16*TNK cins) tile of dW for ALL nine taps and walks a chunk of
+// 4 x 16 pixel tiles: per tile it stages the dy tile (64 pixels) and the (4+2) x 18 x patch ONCE (split on the
+// fly, bf16 pieces, [pixel][channel] images) and its three waves -- wave = kernel row kh -- read transposed
+// fragments for their three taps kw from the same patch at shifted pixel positions.  The block keeps its
+// 3 x TNK x TNK accumulator tiles per wave in registers over the whole chunk and writes them with PLAIN stores
+// into its own slab of a workspace [chunk][Cout][9][Cin]; wgrad9_reduce_kernel then adds the chunks to dW in
+// index order: no atomics, no cross-wave reduction, and the gradient is bit-reproducible run to run.
+template <int NS, int TNK>
+struct SpWgrad9Lds {
+  static constexpr int S = sp_row_stride(16 * TNK);     // bytes per pixel row (both images)
+  static constexpr int DYPIX = 64, XPIX = 6 * 18;
+  static constexpr int PIECE = (DYPIX + XPIX) * S;
+  static constexpr int BYTES = NS * PIECE;
+};
+
+struct Wgrad9Args {
+  const float* x; const float* dy; float* ws;     // ws: [nchunks][Cout][9][Cin]
+  int ldx, lddy, B, H, W, Cin, Cout;
+  int tiles_x, tiles_y, ntiles, nchunks, per;      // per = tiles per chunk
+};
+
+template <int NS, int TNK>
+__device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned char* lds, const int pair, const int chunk) {
+  using L = SpWgrad9Lds<NS, TNK>;
+  constexpr int S = L::S, PIECE = L::PIECE, XBASE = L::DYPIX * S;
+  constexpr int GPP = TNK * 4;                               // 16-byte granules per pixel
+  constexpr int DYG = L::DYPIX * GPP, NG = (L::DYPIX + L::XPIX) * GPP;
+  constexpr int NT = 192, LOADS = (NG + NT - 1) / NT;
+  static_assert(NG >= NT, "spare lanes of the last round repeat a granule of the round before");
+  const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;     // wave = kernel row
+  const int g = lane >> 4, li = lane & 15;
+  const int nkt = p.Cin / (16 * TNK);
+  const int ct = pair / nkt, kt = pair - ct * nkt;
+  const int n0 = ct * 16 * TNK, k0 = kt * 16 * TNK;
+  const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
+
+  f32x4 rg[LOADS];
+  auto tile_load = [&](int t) {
+    const int tx = t % p.tiles_x;
+    int r = t / p.tiles_x;
+    const int ty = r % p.tiles_y, b = r / p.tiles_y;
+    const int y0 = ty * 4, x0 = tx * 16;
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int f = tid + NT * i;
+      if (f >= NG) f -= NT;
+      if (f < DYG) {
+        const int pix = f / GPP, q = f - pix * GPP;
+        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
+        const bool ok = (iy < p.H) & (ix < p.W);
+        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
+        rg[i] = buf_load4(rdy, off, 0);
+      } else {
+        const int fx = f - DYG;
+        const int pix = fx / GPP, q = fx - pix * GPP;
+        const int py = pix / 18, px = pix - py * 18;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
+        rg[i] = buf_load4(rx, off, 0);
+      }
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int f = tid + NT * i;
+      if (f >= NG) f -= NT;
+      u32x2 pc[NS];
+      sp_split4<NS>(rg[i], pc);
+      // both images are [pixel][S bytes]: the x patch follows the dy tile, so granule f sits at pixel f / GPP
+      const int pix = f / GPP, q = f - pix * GPP;
+      const int o = pix * S + q * 8;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + o) = pc[s];
+    }
+  };
+
+  f32x4 acc[3][TNK][TNK];
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int n = 0; n < TNK; ++n)
+#pragma unroll
+      for (int k = 0; k < TNK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read lane offsets: lane 16g+i supplies row (i>>2) of a 4-pixel block, columns 4(i&3)..+3
+  const int lrow = li >> 2, lcol = (li & 3) * 8;
+  const int dy_lane = (4 * g + lrow) * S + lcol;                              // + (2ks+h)*16*S + n*32
+  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * S + lcol;             // + ((2ks+h)*18 + kw)*S + k*32
+
+  if (t_lo < t_hi) tile_load(t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
+    __syncthreads();                         // every wave is done with the previous tile's images
+    tile_store();
+    if (t + 1 < t_hi) tile_load(t + 1);      // in flight behind this tile's MFMAs
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 afr[TNK][NS];
+#pragma unroll
+      for (int n = 0; n < TNK; ++n)
+#pragma unroll
+        for (int pc = 0; pc < NS; ++pc) {
+          const s16x4 v0 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks) * 16 * S + n * 32);
+          const s16x4 v1 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * S + n * 32);
+          afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+        }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        bf16x8 bfr[TNK][NS];
+#pragma unroll
+        for (int k = 0; k < TNK; ++k)
+#pragma unroll
+          for (int pc = 0; pc < NS; ++pc) {
+            const s16x4 v0 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
+            const s16x4 v1 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
+            bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+          }
+#pragma unroll
+        for (int n = 0; n < TNK; ++n)
+#pragma unroll
+          for (int k = 0; k < TNK; ++k) acc[kw][n][k] = sp_mma<NS>(afr[n], bfr[k], acc[kw][n][k]);
+      }
+    }
+  }
+
+  // this block's slab of the workspace: plain stores, every element written by exactly one lane
+  float* out = p.ws + (size_t)chunk * p.Cout * 9 * p.Cin;
+  const int row9 = 9 * p.Cin;
+  const int obase = ((n0 + 4 * g) * 9 + kh * 3) * p.Cin + k0 + li;     // D row = 4*(lane>>4)+reg, D col = lane&15
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int n = 0; n < TNK; ++n)
+#pragma unroll
+      for (int k = 0; k < TNK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = acc[kw][n][k][e];
+}
+
+#define WG9_MAXG 8
+struct Wgrad9Group {
+  int n;
+  int blk_end[WG9_MAXG];
+  Wgrad9Args a[WG9_MAXG];
+};
+template <int NS, int TNK>
+__device__ __forceinline__ void wgrad9_sp_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
+  int gi = 0;
+  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
+  const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
+  const Wgrad9Args& p = grp.a[gi];
+  const int npairs = (p.Cout / (16 * TNK)) * (p.Cin / (16 * TNK));
+  wgrad9_sp_body<NS, TNK>(p, lds, local % npairs, local / npairs);     // the tile pairs of one chunk are neighbours: same pixels
+}
+// 48-channel tiles: capped at 256 registers so that two blocks (six waves) share a CU
+template <int NS>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad9_sp_group_kernel3(Wgrad9Group grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9Lds<NS, 3>::BYTES];
+  wgrad9_sp_group_entry<NS, 3>(grp, lds);
+}
+// 64-channel tiles: 3 x 16 accumulator tiles per wave, one block per CU
+template <int NS>
+__global__ __launch_bounds__(192) void wgrad9_sp_group_kernel4(Wgrad9Group grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9Lds<NS, 4>::BYTES];
+  wgrad9_sp_group_entry<NS, 4>(grp, lds);
+}
+
+// dW[i] += sum over chunks (in chunk order) of ws[chunk][i]; n4 = elements / 4 per problem
+struct Wgrad9Reduce {
+  int n;
+  int blk_end[WG9_MAXG];
+  const float* ws[WG9_MAXG];
+  float* dw[WG9_MAXG];
+  int nchunks[WG9_MAXG];
+  long n4[WG9_MAXG];
+};
+__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(Wgrad9Reduce r) {
+  // block = 32 consecutive float4 x 8 chunk groups (group j sums chunks j, j+8, ... in order); the eight partial
+  // sums meet in LDS and are added in a fixed tree order: the same bits every run
+  __shared__ f32x4 part[8][32];
+  int gi = 0;
+  while (gi + 1 < r.n && (int)blockIdx.x >= r.blk_end[gi]) ++gi;
+  const int lo = gi ? r.blk_end[gi - 1] : 0;
+  const long n4 = r.n4[gi];
+  const f32x4* ws = reinterpret_cast<const f32x4*>(r.ws[gi]);
+  f32x4* dw = reinterpret_cast<f32x4*>(r.dw[gi]);
+  const int nch = r.nchunks[gi];
+  const int e = threadIdx.x & 31, j = threadIdx.x >> 5;
+  for (long i0 = (long)(blockIdx.x - lo) * 32; i0 < n4; i0 += (long)(r.blk_end[gi] - lo) * 32) {
+    const long i = i0 + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+      for (int c = j; c < nch; c += 8) s += ws[(size_t)c * n4 + i];
+    part[j][e] = s;
+    __syncthreads();
+    if (j == 0 && i < n4)
+      dw[i] += ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]));
+    __syncthreads();
+  }
 }

@@ -100,6 +100,8 @@ def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0):
 
 def conv_wgrad(x, dy, dw, k, s, prec=0):
     """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
+    if prec and k == 3 and s == 1:
+        return conv_wgrad_group([x], [dy], [dw], k, s, prec)
     sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec)
     call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
 
@@ -136,9 +138,15 @@ def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0):
 
 
 def conv_wgrad_group(xs, dys, dws, k, s, prec=0):
-    shapes = [_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec) for x, dy in zip(xs, dys)]
-    call("hrseg_conv_wgrad_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(dys), _lib.ptr_array(dws),
-         _shape_array(shapes))
+    shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec) for x, dy in zip(xs, dys)])
+    nbytes = _lib.conv_wgrad_workspace_bytes(shapes) if (prec and k == 3 and s == 1) else 0
+    if nbytes:
+        # split-precision 3x3 stride-1 problems: per-block partial sums in a workspace + ordered reduce (no atomics)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=xs[0].device)
+        call("hrseg_conv_wgrad_group_ws", len(xs), _lib.ptr_array(xs), _lib.ptr_array(dys), _lib.ptr_array(dws), shapes,
+             ptr(ws), nbytes)
+        return
+    call("hrseg_conv_wgrad_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(dys), _lib.ptr_array(dws), shapes)
 
 
 def weight_transpose(w_store, Cout, taps, Cin, out=None):
@@ -149,10 +157,13 @@ def weight_transpose(w_store, Cout, taps, Cin, out=None):
 
 
 # ------------------------------------------------------------------ batch norm
+_BN_MAX_CHUNKS = int(os.environ.get("HRSEG_BN_MAX_CHUNKS", "256"))     # pixel chunks (= blocks) per BatchNorm reduction
+
+
 def _nchunks(npix, Cn):
     q = Cn // 4
     p = 1 if q >= 256 else 256 // q
-    return max(1, min(256, npix // (8 * p)))
+    return max(1, min(_BN_MAX_CHUNKS, npix // (8 * p)))
 
 
 def bn_train_coef(y, gamma, beta, running_mean, running_var, nbt, momentum, eps):

