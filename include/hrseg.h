@@ -59,13 +59,21 @@ int hrseg_abi_version(void);
  *   BF16X2  2 pieces, 3 products (operand error 2^-16)
  *   BF16    operands rounded to bf16, fp32 accumulation (BASELINE configs[4] arithmetic)
  *   AUTO    fp32-grade results from the faster family per problem: BF16X3 for forward / data-gradient
- *           problems of at least 8192 output pixels, F32 for small ones and for weight gradients         */
-enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3, HRSEG_CONV_AUTO = 4 };
+ *           problems of at least 8192 output pixels, F32 for small ones and for weight gradients
+ *   FP16X2  each operand scaled by a power of two and split into 2 fp16 pieces (22 significand bits), the 3
+ *           largest piece products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: operand error 2^-22 at
+ *           half the matrix work of BF16X3.  Weights are scaled by 2^8, gradient operands by 2^14 / |max|
+ *           (`grad_absmax`, written by hrseg_bn_bwd_group), activations are clamped to +-65504.            */
+enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3, HRSEG_CONV_AUTO = 4,
+                            HRSEG_CONV_FP16X2 = 5 };
 typedef struct {
   int B, Hi, Wi, Cin, ldx; /* input  x[B,Hi,Wi,Cin], row stride ldx   */
   int Ho, Wo, Cout, ldy;   /* output y[B,Ho,Wo,Cout], row stride ldy  */
   int ksize, stride;       /* 1 or 3 ; 1 or 2                          */
   int precision;           /* hrseg_conv_precision                     */
+  const float* grad_absmax; /* FP16X2, data / weight gradient: DEVICE array of 64 floats whose maximum is max|dy|
+                               of the gradient operand (hrseg_bn_bwd_t.dy_absmax writes it; NULL: unscaled --
+                               gradients below 6e-5 then lose precision)                                   */
 } hrseg_conv_shape_t;
 
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */
@@ -177,6 +185,9 @@ typedef struct {
   float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
   long npix; int C;
   double* partial; int nchunks;                      /* scratch (nchunks+max(nseg,1))*2*C doubles   */
+  float* dy_absmax;                                  /* optional DEVICE array of 64 floats, zeroed by the caller:
+                                                        slot (block % 64) receives the max|dy| of its blocks;
+                                                        feeds hrseg_conv_shape_t.grad_absmax              */
   int nseg;                                          /* > 1: npix is nseg equal segments (the batched
                                                         level passes), each normalised on its own: the
                                                         batch means of the backward are per segment;

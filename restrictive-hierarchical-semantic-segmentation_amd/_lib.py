@@ -31,11 +31,12 @@ _f = C.c_float
 
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
-    _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")]
+    _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")] + \
+               [("grad_absmax", _p)]
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
-CONV_PRECISION = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "bf16": 3, "auto": 4}
+CONV_PRECISION = {"f32": 0, "bf16x3": 1, "bf16x2": 2, "bf16": 3, "auto": 4, "fp16x2": 5}
 
 
 class BnFwd(C.Structure):
@@ -50,7 +51,7 @@ class BnBwd(C.Structure):
     """hrseg_bn_bwd_t"""
     _fields_ = [("dz", _p), ("lddz", _i), ("z", _p), ("ldz", _i), ("relu", _i), ("y", _p), ("ldy", _i), ("coef", _p),
                 ("dgamma", _p), ("dbeta", _p), ("dy", _p), ("lddy", _i), ("dres", _p), ("lddres", _i),
-                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("nseg", _i)]
+                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("dy_absmax", _p), ("nseg", _i)]
 
 
 # name -> argtypes, exactly the prototypes of include/hrseg.h

@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
   const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
   const int C = p.C;
   const Lanes L = make_lanes(C);
-  if (!L.active) return;
+  float amax = 0.f;
+  if (L.active) {                 // (no early return: every lane takes part in the max reduction below)
   const double* totals = p.partial + (size_t)p.nchunks * 2 * C;
   const f32x4 mean = ld4(p.coef + 4 * L.cq), rstd = ld4(p.coef + C + 4 * L.cq), scale = ld4(p.coef + 2 * C + 4 * L.cq);
   const f32x4 shift = ld4(p.coef + 3 * C + 4 * L.cq);
@@ -822,12 +823,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
       for (int j = 0; j < 4; ++j) gg[j] = zz[j] > 0.f ? gg[j] : 0.f;
     }
     const f32x4 xh = (yv - mean) * rstd;
-    st4(p.dy + pix * p.lddy + 4 * L.cq, scale * (gg - mg - xh * mgx));
+    const f32x4 dyv = scale * (gg - mg - xh * mgx);
+    st4(p.dy + pix * p.lddy + 4 * L.cq, dyv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(dyv[j]));
     if (p.dres) {
       float* d = p.dres + pix * p.lddres + 4 * L.cq;
       st4(d, p.dres_accumulate ? ld4(d) + gg : gg);
     }
   }
+  }
+  }
+  if (p.dy_absmax) {
+    // max|dy| of the tensor into slot (block % 64) of a 64-entry array (non-negative floats order like their bit
+    // patterns): one atomic per block, at most grid/64 per address -- a single address serialises ~4000 blocks
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.dy_absmax) + (blockIdx.x & 63), __float_as_uint(m));
+    }
   }
 }
 

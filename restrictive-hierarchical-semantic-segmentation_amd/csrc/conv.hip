@@ -41,6 +41,8 @@ struct IgemmArgs {
   int accumulate;            // y += result
   float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
   int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
+  const float* xmax;         // fp16x2: device scalar max|x| of the pixel operand when it is a gradient (else null)
+  float wscale, wscale_inv;  // fp16x2: fixed power-of-two scale of the weight operand and its inverse (1 otherwise)
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
 };
 
@@ -303,6 +305,7 @@ struct WgradArgs {
   int ks, stride, T;
   int pix_per_block;  // multiple of the stage size
   float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
+  const float* dymax;   // fp16x2: device scalar max|dy| (null: unscaled)
 };
 
 #include "conv_sp.h"
@@ -497,8 +500,17 @@ static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
   return HRSEG_ERR_UNSUPPORTED;
 }
 
-static int sp_pieces(int precision) {    // hrseg_conv_precision -> bf16 pieces per operand (0: the fp32 MFMA kernels)
-  return precision == HRSEG_CONV_BF16X3 ? 3 : precision == HRSEG_CONV_BF16X2 ? 2 : precision == HRSEG_CONV_BF16 ? 1 : 0;
+static int sp_pieces(int precision) {    // hrseg_conv_precision -> split scheme of conv_sp.h (0: the fp32 MFMA kernels)
+  return precision == HRSEG_CONV_BF16X3 ? 3 : precision == HRSEG_CONV_BF16X2 ? 2 : precision == HRSEG_CONV_BF16 ? 1
+       : precision == HRSEG_CONV_FP16X2 ? 4 : 0;
+}
+// fp16x2: weights are scaled by a fixed 2^8 before the split (|w| up to 255 stays in fp16 range, typical
+// |w| ~ 0.01-1 keeps its low piece out of the subnormals)
+static void set_sp_scales(IgemmArgs& a, int precision, const float* grad_absmax) {
+  const bool f16 = precision == HRSEG_CONV_FP16X2;
+  a.wscale = f16 ? 256.f : 1.f;
+  a.wscale_inv = f16 ? 1.f / 256.f : 1.f;
+  a.xmax = f16 ? grad_absmax : nullptr;
 }
 
 // HRSEG_CONV_AUTO: fp32-grade results from whichever kernel family is faster for the problem (measured on
@@ -516,12 +528,11 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
   if (const int ns = sp_pieces(precision)) {
     const SpPlan pl = plan_sp(a);
     if (const int cs = patch_cs(a, pl.wtn)) {
-      const int rc = ns == 3 ? launch_patch_sp<3>(a, pl.wtn, cs, st) : ns == 2 ? launch_patch_sp<2>(a, pl.wtn, cs, st)
-                                                                                 : launch_patch_sp<1>(a, pl.wtn, cs, st);
+      const int rc = ns == 4 ? launch_patch_sp<4>(a, pl.wtn, cs, st) : ns == 3 ? launch_patch_sp<3>(a, pl.wtn, cs, st) : ns == 2 ? launch_patch_sp<2>(a, pl.wtn, cs, st) : launch_patch_sp<1>(a, pl.wtn, cs, st);
       if (rc == 0) return 0;
     }
     if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
-    return ns == 3 ? launch_sp<3>(a, pl, st) : ns == 2 ? launch_sp<2>(a, pl, st) : launch_sp<1>(a, pl, st);
+    return ns == 4 ? launch_sp<4>(a, pl, st) : ns == 3 ? launch_sp<3>(a, pl, st) : ns == 2 ? launch_sp<2>(a, pl, st) : launch_sp<1>(a, pl, st);
   }
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
@@ -661,8 +672,7 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     g.kind[o] = kind[i];
     g.a[o] = fa[i];
   }
-  if (ns) return ns == 3 ? launch_sp_group<3>(g, wtm, wtn, group_cs, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, group_cs, st)
-                                                                                      : launch_sp_group<1>(g, wtm, wtn, group_cs, st);
+  if (ns) return ns == 4 ? launch_sp_group<4>(g, wtm, wtn, group_cs, st) : ns == 3 ? launch_sp_group<3>(g, wtm, wtn, group_cs, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, group_cs, st) : launch_sp_group<1>(g, wtm, wtn, group_cs, st);
   if (wtm == 2 && wtn == 3 && kc == 3) launch_igemm_group<2, 3, 3, 1>(g, st);
   else if (wtm == 2 && wtn == 3) launch_igemm_group<2, 3, 1, 1>(g, st);
   else if (wtm == 2) return 1;
@@ -1130,6 +1140,7 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
     Wgrad9Args& a = g.a[i];
     wgrad9_plan(shapes[i], tnk, a);
     a.x = x[i]; a.dy = dy[i]; a.ws = ws;
+    a.dymax = shapes[i].precision == HRSEG_CONV_FP16X2 ? shapes[i].grad_absmax : nullptr;
     HRSEG_CHECK_ARG((double)shapes[i].Hi * shapes[i].Wi * (double)(shapes[i].ldx > shapes[i].ldy ? shapes[i].ldx : shapes[i].ldy) * 4.0 < 4294967296.0,
                     "wgrad9: one image exceeds the 4 GB buffer-offset range");
     const long elems = (long)shapes[i].Cout * 9 * shapes[i].Cin;
@@ -1143,7 +1154,7 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
 #define W9(NS_) if (ns == NS_) { \
     if (tnk == 3) hipLaunchKernelGGL((wgrad9_sp_group_kernel3<NS_>), dim3(end), dim3(192), 0, st, g); \
     else hipLaunchKernelGGL((wgrad9_sp_group_kernel4<NS_>), dim3(end), dim3(192), 0, st, g); }
-  W9(1) W9(2) W9(3)
+  W9(1) W9(2) W9(3) W9(4)
 #undef W9
   HRSEG_LAUNCH_CHECK("wgrad9");
   hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rend), dim3(256), 0, st, r);
@@ -1193,7 +1204,7 @@ __global__ void weight_transpose_all_kernel(const float* __restrict__ flat, floa
 static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(s != nullptr, "%s: null shape", who);
   HRSEG_CHECK_ARG(s->ksize == 1 || s->ksize == 3, "%s: ksize %d not in {1,3}", who, s->ksize);
-  HRSEG_CHECK_ARG(s->precision >= HRSEG_CONV_F32 && s->precision <= HRSEG_CONV_AUTO, "%s: precision %d is not a hrseg_conv_precision",
+  HRSEG_CHECK_ARG(s->precision >= HRSEG_CONV_F32 && s->precision <= HRSEG_CONV_FP16X2, "%s: precision %d is not a hrseg_conv_precision",
                   who, s->precision);
   HRSEG_CHECK_ARG(s->stride == 1 || s->stride == 2, "%s: stride %d not in {1,2}", who, s->stride);
   HRSEG_CHECK_ARG(s->B > 0 && s->Hi > 0 && s->Wi > 0 && s->Cin > 0 && s->Cout > 0, "%s: non-positive dims", who);
@@ -1230,6 +1241,7 @@ static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const fl
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
+  set_sp_scales(a, s->precision, nullptr);
 }
 
 // stride-1 data gradient as a forward-style gather over dy with the transposed weights
@@ -1246,6 +1258,7 @@ static void fill_dgrad_s1_args(IgemmArgs& a, const float* dy, const float* wt, f
   int oy[9], ox[9], wtp[9];
   for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
   pack_taps(a, a.T, oy, ox, wtp);
+  set_sp_scales(a, s->precision, s->grad_absmax);
 }
 
 static void fill_wgrad_args(WgradArgs& a, const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s) {
@@ -1256,6 +1269,7 @@ static void fill_wgrad_args(WgradArgs& a, const float* x, const float* dy, float
   const bool big = (long)s->B * s->Ho * s->Wo >= (1L << 24);   // float-reciprocal division is exact below 2^24
   a.rcp_hw = big ? 0.f : 1.0f / (float)(s->Ho * s->Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
+  a.dymax = s->precision == HRSEG_CONV_FP16X2 ? s->grad_absmax : nullptr;
 }
 
 static bool mfma_shape(const hrseg_conv_shape_t* s) {
@@ -1378,6 +1392,7 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   const int pad = (s->ksize - 1) / 2;
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
+  set_sp_scales(a, s->precision, nullptr);
   if (int e = dispatch_igemm(a, s->precision, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;
@@ -1396,6 +1411,7 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
   a.B = s->B; a.Hi = s->Ho; a.Wi = s->Wo; a.K = s->Cout;  // GEMM input = dy
   a.N = s->Cin; a.T = s->ksize * s->ksize; a.accumulate = accumulate;
   a.Hy = s->Hi; a.Wy = s->Wi;
+  set_sp_scales(a, s->precision, s->grad_absmax);
   const int ks = s->ksize, pad = (ks - 1) / 2;
   if (s->stride == 1) {
     a.Ho = s->Hi; a.Wo = s->Wi; a.M = s->B * s->Hi * s->Wi;
@@ -1470,8 +1486,9 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   const bool big = (long)s->B * s->Ho * s->Wo >= (1L << 24);   // float-reciprocal division is exact below 2^24
   a.rcp_hw = big ? 0.f : 1.0f / (float)(s->Ho * s->Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
+  a.dymax = s->precision == HRSEG_CONV_FP16X2 ? s->grad_absmax : nullptr;
   if (const int ns = sp_pieces(s->precision)) {
-    if (int e = ns == 3 ? dispatch_wgrad_sp<3>(a, st) : ns == 2 ? dispatch_wgrad_sp<2>(a, st) : dispatch_wgrad_sp<1>(a, st)) return e;
+    if (int e = ns == 4 ? dispatch_wgrad_sp<4>(a, st) : ns == 3 ? dispatch_wgrad_sp<3>(a, st) : ns == 2 ? dispatch_wgrad_sp<2>(a, st) : dispatch_wgrad_sp<1>(a, st)) return e;
     HRSEG_LAUNCH_CHECK("wgrad_sp");
     return 0;
   }

@@ -39,51 +39,107 @@ __device__ __forceinline__ unsigned sp_pack_rne(float lo, float hi) {
 }
 __device__ __forceinline__ float sp_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
 
-// 8 fp32 (two f32x4: k = 0..3 and 4..7 of this lane's fragment) -> NS bf16x8 fragments
-template <int NS>
-__device__ __forceinline__ void sp_split8(const f32x4& a, const f32x4& b, bf16x8 (&out)[NS]) {
-  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+// Scheme codes (template parameter NS): 1, 2, 3 = that many bf16 pieces; 4 = "fp16x2": two fp16 pieces (11
+// significand bits each: hi = round-toward-zero(x), lo = round-to-nearest(x - hi), 22 bits in all) and the three
+// products hi*hi, hi*lo, lo*hi on v_mfma_f32_16x16x32_f16 -- half the matrix work of bf16x3 at 2^-22 operand
+// error.  fp16 has 5 exponent bits, so fp16x2 operands are SCALED by a power of two before the split (weights by a
+// fixed 2^8, gradients by 2^14 / their measured |max|, see sp_pow2_scale) and the accumulators are scaled back in
+// the epilogue; activations are clamped to the fp16 range.  Elements more than 2^19 below the scaled maximum
+// lose their low piece to the subnormal range (absolute error <= 2^-25 after scaling): invisible in a dot product.
+constexpr int sp_np(int ns) { return ns == 4 ? 2 : ns; }                       // pieces per operand
+constexpr int sp_products(int ns) { return ns == 1 ? 1 : ns == 3 ? 6 : 3; }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// power-of-two scale that brings the tensor's |max| into [2^14, 2^15) and its inverse (1, 1 for 0 / denormal /
+// absent).  `absmax` is the 64-slot array hrseg_bn_bwd_group fills (each slot the max over a share of the blocks).
+__device__ __forceinline__ void sp_pow2_scale(const float* absmax, float& scale, float& inv) {
+  scale = inv = 1.f;
+  if (!absmax) return;
+  float m = absmax[threadIdx.x & 63];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    u32x4 u;
-    const bool last = s == NS - 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      u[j] = (last && NS < 3) ? sp_pack_rne(x[2 * j], x[2 * j + 1]) : sp_pack_trunc(x[2 * j], x[2 * j + 1]);
-    out[s] = __builtin_bit_cast(bf16x8, u);
-    if (!last) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] -= sp_trunc(x[j]);
-    }
-  }
-}
-// 4 fp32 -> NS x 4 bf16 (8 bytes per piece): the weight staging granule
-template <int NS>
-__device__ __forceinline__ void sp_split4(const f32x4& a, u32x2 (&out)[NS]) {
-  float x[4] = {a[0], a[1], a[2], a[3]};
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const bool last = s == NS - 1;
-    if (last && NS < 3) out[s] = u32x2{sp_pack_rne(x[0], x[1]), sp_pack_rne(x[2], x[3])};
-    else out[s] = u32x2{sp_pack_trunc(x[0], x[1]), sp_pack_trunc(x[2], x[3])};
-    if (!last) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] -= sp_trunc(x[j]);
-    }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const unsigned e = (__float_as_uint(m) >> 23) & 255u;
+  if (e >= 16u && e <= 250u) {
+    scale = __uint_as_float((268u - e) << 23);
+    inv = __uint_as_float((e - 14u) << 23);
   }
 }
 
-// acc += W-fragment pieces x X-fragment pieces: the products whose weight is at least 2^-16 of the full product
+__device__ __forceinline__ unsigned sp_pack_f16_rtz(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+__device__ __forceinline__ unsigned sp_pack_f16_rne(float lo, float hi) {
+  const f16x2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float sp_f16_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2, pk)[0]; }
+__device__ __forceinline__ float sp_f16_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2, pk)[1]; }
+
+// N fp32 (N = 4 or 8, N/2 dwords per piece) -> sp_np(NS) pieces; `sc` scales first (fp16x2 only)
+template <int NS, int N>
+__device__ __forceinline__ void sp_split(float (&x)[N], unsigned (&out)[sp_np(NS)][N / 2], float sc) {
+  if (NS == 4) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j] * sc, -65504.f, 65504.f);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      const unsigned hi = sp_pack_f16_rtz(x[2 * j], x[2 * j + 1]);
+      out[0][j] = hi;
+      out[1][j] = sp_pack_f16_rne(x[2 * j] - sp_f16_lo(hi), x[2 * j + 1] - sp_f16_hi(hi));
+    }
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < sp_np(NS); ++s) {
+    const bool last = s == NS - 1;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j)
+      out[s][j] = (last && NS < 3) ? sp_pack_rne(x[2 * j], x[2 * j + 1]) : sp_pack_trunc(x[2 * j], x[2 * j + 1]);
+    if (!last) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] -= sp_trunc(x[j]);
+    }
+  }
+}
+// 8 fp32 (two f32x4: k = 0..3 and 4..7 of this lane's fragment) -> fragments (128-bit, typed bf16x8 whatever the scheme)
 template <int NS>
-__device__ __forceinline__ f32x4 sp_mma(const bf16x8 (&w)[NS], const bf16x8 (&x)[NS], f32x4 acc) {
+__device__ __forceinline__ void sp_split8(const f32x4& a, const f32x4& b, bf16x8 (&out)[sp_np(NS)], float sc = 1.f) {
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  unsigned u[sp_np(NS)][4];
+  sp_split<NS, 8>(x, u, sc);
+#pragma unroll
+  for (int s = 0; s < sp_np(NS); ++s) out[s] = __builtin_bit_cast(bf16x8, (u32x4){u[s][0], u[s][1], u[s][2], u[s][3]});
+}
+// 4 fp32 -> pieces of 4 elements (8 bytes each): the staging granule
+template <int NS>
+__device__ __forceinline__ void sp_split4(const f32x4& a, u32x2 (&out)[sp_np(NS)], float sc = 1.f) {
+  float x[4] = {a[0], a[1], a[2], a[3]};
+  unsigned u[sp_np(NS)][2];
+  sp_split<NS, 4>(x, u, sc);
+#pragma unroll
+  for (int s = 0; s < sp_np(NS); ++s) out[s] = u32x2{u[s][0], u[s][1]};
+}
+
+// acc += W-fragment pieces x X-fragment pieces: the products whose weight is at least 2^-16 (bf16) / 2^-11 (fp16)
+// of the full product
+template <int NS>
+__device__ __forceinline__ f32x4 sp_mma(const bf16x8 (&w)[sp_np(NS)], const bf16x8 (&x)[sp_np(NS)], f32x4 acc) {
+  if (NS == 4) {
+    const f16x8 w0 = __builtin_bit_cast(f16x8, w[0]), w1 = __builtin_bit_cast(f16x8, w[1]);
+    const f16x8 x0 = __builtin_bit_cast(f16x8, x[0]), x1 = __builtin_bit_cast(f16x8, x[1]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x1, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x0, acc, 0, 0, 0);
+  }
   if (NS == 3) {   // smallest terms first
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[sp_np(NS) - 1], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[sp_np(NS) - 1], acc, 0, 0, 0);
   }
   if (NS >= 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1 % sp_np(NS)], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1 % sp_np(NS)], acc, 0, 0, 0);
   }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc, 0, 0, 0);
 }
@@ -92,7 +148,7 @@ template <int NS, int WTN>
 struct SpLds {
   static constexpr int BN = 16 * WTN;
   static constexpr int PIECE = BN * 64;          // bytes: one slab of one piece, [BN rows][32 bf16]
-  static constexpr int STAGE = NS * PIECE;       // one buffer
+  static constexpr int STAGE = sp_np(NS) * PIECE;       // one buffer
   static constexpr int BYTES = 2 * STAGE;        // double buffered
 };
 
@@ -110,6 +166,10 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
   const int ntn = p.N / BN;
   const int wg = xcd_remap(bid, nblk);
   const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+
+  float xscale, xinv;                       // fp16x2: power-of-two scale of the pixel operand (a gradient: from its |max|)
+  sp_pow2_scale(p.xmax, xscale, xinv);
+  const float oscale = xinv * p.wscale_inv;
 
   // reduction index: units of 16 channels, u = tap * kch + chunk; a slab = units 2s, 2s+1
   const int kch = p.K >> 4;
@@ -203,20 +263,20 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
     u_next += 2;
   };
 
-  bf16x8 xf[WTM][NS];
+  bf16x8 xf[WTM][sp_np(NS)];
   auto split_store = [&](int buf) {
     unsigned char* base = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
-      u32x2 pc[NS];
-      sp_split4<NS>(rwt[i], pc);
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(rwt[i], pc, p.wscale);
       if (tid + 256 * i < WG) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(base + s * PIECE + wst[i]) = pc[s];
+        for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(base + s * PIECE + wst[i]) = pc[s];
       }
     }
 #pragma unroll
-    for (int m = 0; m < WTM; ++m) sp_split8<NS>(ra[m][0], ra[m][1], xf[m]);
+    for (int m = 0; m < WTM; ++m) sp_split8<NS>(ra[m][0], ra[m][1], xf[m], xscale);
   };
 
   f32x4 acc[WTN][WTM];
@@ -238,9 +298,9 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
     const unsigned char* base = lds + (s & 1) * STAGE;
 #pragma unroll
     for (int n = 0; n < WTN; ++n) {
-      bf16x8 wf[NS];
+      bf16x8 wf[sp_np(NS)];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
+      for (int q = 0; q < sp_np(NS); ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
 #pragma unroll
       for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma<NS>(wf, xf[m], acc[n][m]);
     }
@@ -266,6 +326,7 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
     for (int n = 0; n < WTN; ++n) {
       const int ch = n0 + 16 * n + 4 * g;
       f32x4 v = acc[n][m];
+      if (NS == 4) v *= oscale;
       if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
       if (split) {
 #pragma unroll
@@ -322,7 +383,7 @@ struct SpWgradLds {
   static constexpr int PIX = 128;
   static constexpr int SA = sp_row_stride(16 * TN), SB = sp_row_stride(16 * TK);
   static constexpr int PIECE = PIX * (SA + SB);
-  static constexpr int STAGE = NS * PIECE;
+  static constexpr int STAGE = sp_np(NS) * PIECE;
   static constexpr int RED = 4 * TK * 256 * 4;            // cross-wave reduction, one row of tiles at a time
   static constexpr int BYTES = (STAGE > RED) ? STAGE : RED;
 };
@@ -346,6 +407,8 @@ __device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char*
   const int hi = min(lo + p.pix_per_block, p.M);
   const int nstages = (hi - lo + PIX - 1) / PIX;
   const int q = tid & 3, r0 = tid >> 2;
+  float dyscale, dyinv;                     // fp16x2: the gradient operand is scaled by 2^14 / 2^floor(log2 |max|)
+  sp_pow2_scale(p.dymax, dyscale, dyinv);
 
   const int hw = p.Ho * p.Wo;
   const int b_lo = lo / hw;
@@ -381,17 +444,17 @@ __device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char*
       const int r = r0 + 64 * i;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        u32x2 pc[NS];
-        sp_split4<NS>(ra[i][j], pc);
+        u32x2 pc[sp_np(NS)];
+        sp_split4<NS>(ra[i][j], pc, dyscale);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + r * SA + (16 * j + 4 * q) * 2) = pc[s];
+        for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + r * SA + (16 * j + 4 * q) * 2) = pc[s];
       }
 #pragma unroll
       for (int j = 0; j < TK; ++j) {
-        u32x2 pc[NS];
+        u32x2 pc[sp_np(NS)];
         sp_split4<NS>(rb[i][j], pc);
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < sp_np(NS); ++s)
           *reinterpret_cast<u32x2*>(lds + s * PIECE + PIX * SA + r * SB + (16 * j + 4 * q) * 2) = pc[s];
       }
     }
@@ -416,20 +479,20 @@ __device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char*
   for (int s = 0; s < nstages; ++s) {
     const bool more = s + 1 < nstages;
     if (more) stage_load(s + 1);
-    bf16x8 bfr[TK][NS];
+    bf16x8 bfr[TK][sp_np(NS)];
 #pragma unroll
     for (int k = 0; k < TK; ++k)
 #pragma unroll
-      for (int pc = 0; pc < NS; ++pc) {
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
         const s16x4 v0 = sp_tr_read(lds + pc * PIECE + boff + k * 32);
         const s16x4 v1 = sp_tr_read(lds + pc * PIECE + boff + k * 32 + 16 * SB);
         bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
       }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
-      bf16x8 afr[NS];
+      bf16x8 afr[sp_np(NS)];
 #pragma unroll
-      for (int pc = 0; pc < NS; ++pc) {
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
         const s16x4 v0 = sp_tr_read(lds + pc * PIECE + aoff + n * 32);
         const s16x4 v1 = sp_tr_read(lds + pc * PIECE + aoff + n * 32 + 16 * SA);
         afr[pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
@@ -459,7 +522,7 @@ __device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char*
       for (int wv = 0; wv < 4; ++wv) v += red[(wv * TK + k) * 256 + tid];
       const int co = n0 + 16 * n + 4 * (l >> 4) + r;  // D row = 4*(lane>>4)+reg
       const int ci = k0 + 16 * k + (l & 15);          // D col = lane&15
-      atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
+      atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, NS == 4 ? v * dyinv : v);
     }
     __syncthreads();
   }
@@ -490,8 +553,8 @@ struct SpPatchLds {
   static constexpr int PP = (TH + 2) * 18;              // patch pixels
   static constexpr int CHUNK = PP * 32;                 // bytes per chunk image
   static constexpr int PPIECE = CS * CHUNK;             // per piece
-  static constexpr int PATCH = NS * PPIECE;
-  static constexpr int WPIECE = 16 * WTN * 64, WSTAGE = NS * WPIECE;
+  static constexpr int PATCH = sp_np(NS) * PPIECE;
+  static constexpr int WPIECE = 16 * WTN * 64, WSTAGE = sp_np(NS) * WPIECE;
   static constexpr int BYTES = PATCH + 3 * WSTAGE;      // weight slabs: three buffers (fragments are read one slab ahead)
 };
 
@@ -526,6 +589,9 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   const int nks = p.K / (16 * CS);
   if (first >= end) return;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (size_t)p.N * p.T * p.K * 4);
+  float xscale, xinv;                       // fp16x2: power-of-two scale of the pixel operand (a gradient: from its |max|)
+  sp_pow2_scale(p.xmax, xscale, xinv);
+  const float oscale = xinv * p.wscale_inv;
 
   struct Geom { int b, y0, x0, n0; };
   auto tile_geom = [&](int t) {       // channel tile fastest, then tile column, tile row, image
@@ -559,15 +625,15 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   auto patch_store = [&]() {
 #pragma unroll
     for (int i = 0; i < P_LOADS; ++i) {
-      u32x2 pc[NS];
-      sp_split4<NS>(rp[i], pc);
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(rp[i], pc, xscale);
       int f = tid + 256 * i;
       if (f >= PG) f -= 256;
       const int pix = f / (CS * 4), rem = f - pix * (CS * 4);
       const int c = rem >> 2, q = rem & 3;
       const int o = c * L::CHUNK + pix * 32 + ((q ^ (2 * ((pix >> 3) & 1))) << 3);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
+      for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
     }
   };
 
@@ -602,10 +668,10 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
     unsigned char* base = lw + wboff;
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
-      u32x2 pc[NS];
-      sp_split4<NS>(rwt[set][i], pc);
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(rwt[set][i], pc, p.wscale);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(base + s * L::WPIECE + wst[i]) = pc[s];
+      for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(base + s * L::WPIECE + wst[i]) = pc[s];
     }
   };
 
@@ -616,7 +682,7 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   const int pbase = prow0 * 32;
 
   // fragments of slab `slab` (compile-time) from the current patch and weight buffer offset wboff
-  auto read_frags = [&](int slab, int wboff, bf16x8 (&xf)[RPW][NS], bf16x8 (&wf)[WTN][NS]) {
+  auto read_frags = [&](int slab, int wboff, bf16x8 (&xf)[RPW][sp_np(NS)], bf16x8 (&wf)[WTN][sp_np(NS)]) {
     const int uA = 2 * slab, uB = 2 * slab + 1;
     const int tA = uA / CS, cA = uA - tA * CS;
     const int tB = (uB < NU) ? uB / CS : 0, cB = (uB < NU) ? uB - tB * CS : 0;
@@ -628,7 +694,7 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
       const int oa = cA * L::CHUNK + pbase + (m * PW + dA) * 32 + ((g ^ (2 * ((pa >> 3) & 1))) << 3);
       const int ob = cB * L::CHUNK + pbase + (m * PW + dB) * 32 + ((g ^ (2 * ((pb >> 3) & 1))) << 3);
 #pragma unroll
-      for (int q = 0; q < NS; ++q) {
+      for (int q = 0; q < sp_np(NS); ++q) {
         const u32x2 lo = *reinterpret_cast<const u32x2*>(lpatch + q * L::PPIECE + oa);
         u32x2 hi = u32x2{0u, 0u};
         if (uB < NU) hi = *reinterpret_cast<const u32x2*>(lpatch + q * L::PPIECE + ob);
@@ -639,7 +705,7 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
 #pragma unroll
     for (int n = 0; n < WTN; ++n)
 #pragma unroll
-      for (int q = 0; q < NS; ++q) wf[n][q] = *reinterpret_cast<const bf16x8*>(base + q * L::WPIECE + n * 1024 + foff);
+      for (int q = 0; q < sp_np(NS); ++q) wf[n][q] = *reinterpret_cast<const bf16x8*>(base + q * L::WPIECE + n * 1024 + foff);
   };
 
   f32x4 acc[WTN][RPW];
@@ -659,6 +725,7 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
       for (int n = 0; n < WTN; ++n) {
         const int ch = q.n0 + 16 * n + 4 * g;
         f32x4 v = acc[n][m];
+        if (NS == 4) v *= oscale;
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
         if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
         *reinterpret_cast<f32x4*>(yrow + ch) = v;
@@ -666,7 +733,7 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
     }
   };
 
-  bf16x8 xfr[2][RPW][NS], wfr[2][WTN][NS];
+  bf16x8 xfr[2][RPW][sp_np(NS)], wfr[2][WTN][sp_np(NS)];
   int t = first;
   Geom cur = tile_geom(t);
   // prologue: patch of the first K stage, weight slabs 0 and 1, fragments of slab 0
@@ -756,11 +823,12 @@ struct SpWgrad9Lds {
   static constexpr int S = sp_row_stride(16 * TNK);     // bytes per pixel row (both images)
   static constexpr int DYPIX = 64, XPIX = 6 * 18;
   static constexpr int PIECE = (DYPIX + XPIX) * S;
-  static constexpr int BYTES = NS * PIECE;
+  static constexpr int BYTES = sp_np(NS) * PIECE;
 };
 
 struct Wgrad9Args {
   const float* x; const float* dy; float* ws;     // ws: [nchunks][Cout][9][Cin]
+  const float* dymax;                              // device scalar |dy|_max (fp16x2 scaling) or null
   int ldx, lddy, B, H, W, Cin, Cout;
   int tiles_x, tiles_y, ntiles, nchunks, per;      // per = tiles per chunk
 };
@@ -779,6 +847,8 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
   const int ct = pair / nkt, kt = pair - ct * nkt;
   const int n0 = ct * 16 * TNK, k0 = kt * 16 * TNK;
   const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
+  float dyscale, dyinv;                     // fp16x2: the gradient operand is scaled by 2^14 / 2^floor(log2 |max|)
+  sp_pow2_scale(p.dymax, dyscale, dyinv);
 
   f32x4 rg[LOADS];
   auto tile_load = [&](int t) {
@@ -814,13 +884,13 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
     for (int i = 0; i < LOADS; ++i) {
       int f = tid + NT * i;
       if (f >= NG) f -= NT;
-      u32x2 pc[NS];
-      sp_split4<NS>(rg[i], pc);
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(rg[i], pc, f < DYG ? dyscale : 1.f);
       // both images are [pixel][S bytes]: the x patch follows the dy tile, so granule f sits at pixel f / GPP
       const int pix = f / GPP, q = f - pix * GPP;
       const int o = pix * S + q * 8;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + o) = pc[s];
+      for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + o) = pc[s];
     }
   };
 
@@ -845,22 +915,22 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 afr[TNK][NS];
+      bf16x8 afr[TNK][sp_np(NS)];
 #pragma unroll
       for (int n = 0; n < TNK; ++n)
 #pragma unroll
-        for (int pc = 0; pc < NS; ++pc) {
+        for (int pc = 0; pc < sp_np(NS); ++pc) {
           const s16x4 v0 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks) * 16 * S + n * 32);
           const s16x4 v1 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * S + n * 32);
           afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
         }
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        bf16x8 bfr[TNK][NS];
+        bf16x8 bfr[TNK][sp_np(NS)];
 #pragma unroll
         for (int k = 0; k < TNK; ++k)
 #pragma unroll
-          for (int pc = 0; pc < NS; ++pc) {
+          for (int pc = 0; pc < sp_np(NS); ++pc) {
             const s16x4 v0 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
             const s16x4 v1 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
             bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
@@ -884,7 +954,8 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
 #pragma unroll
       for (int k = 0; k < TNK; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = acc[kw][n][k][e];
+        for (int e = 0; e < 4; ++e)
+          out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
 }
 
 #define WG9_MAXG 8

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 # Weight gradients are off the critical path of the reverse pass (nothing reads them before the
 # all-reduce / optimizer), so they run on a second HIP stream next to the data-gradient + BN chain:
@@ -240,8 +240,13 @@ class Recorder:
         coefs = [c for _, c in zc]
         eval_mode = not self.training
 
+        want_gmax = self.prec == _lib.CONV_PRECISION["fp16x2"]
+
         def bwd():
             bw = []
+            # fp16x2: the BN backward records max|dy| per problem; the data / weight gradients scale dy by it
+            gmax_all = ops.zeros((n, 64), torch.float32, ys[0].device) if want_gmax else None
+            gmaxs = [gmax_all[i] for i in range(n)] if want_gmax else [None] * n
             for i, ((x, conv, bn, res), y, z, coef) in enumerate(zip(items, ys, zs, coefs)):
                 dz = z.grad
                 z.grad = None
@@ -255,18 +260,21 @@ class Recorder:
                 # without a residual the ReLU mask is recomputed from y: the backward never reads z
                 bw.append(dict(dz=dz, z=z.data if (relus[i] and res is not None) else None, relu=relus[i], y=y, coef=coef,
                                dgamma=bn.weight._hr_gstore,
-                               dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments))
+                               dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments,
+                               dy_absmax=gmaxs[i]))
             dys = ops.bn_bwd_group(bw, eval_mode)
             side = wgrad_stream(dys[0].device)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 if n == 1:
-                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec)
+                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0])
                 else:
                     ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
-                                         prec=self.prec)
+                                         prec=self.prec, gmaxs=gmaxs)
             if side is not None:
+                if gmax_all is not None:
+                    gmax_all.record_stream(side)
                 for t in dys:
                     t.record_stream(side)     # not reused before the side stream is done reading it
                 for x in xs:
@@ -283,14 +291,16 @@ class Recorder:
                     i = rnd[0]
                     x = xs[i]
                     if x.grad is None:
-                        x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, prec=self.prec)
+                        x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, prec=self.prec,
+                                                gmax=gmaxs[i])
                     else:
                         ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, out=x.grad, accumulate=True,
-                                       prec=self.prec)
+                                       prec=self.prec, gmax=gmaxs[i])
                 else:
                     got = ops.conv_dgrad_group([dys[i] for i in rnd], [self._wt(items[i][1]) for i in rnd],
                                                [xs[i].data.shape for i in rnd], k, s, [xs[i].grad for i in rnd],
-                                               [xs[i].grad is not None for i in rnd], prec=self.prec)
+                                               [xs[i].grad is not None for i in rnd], prec=self.prec,
+                                               gmaxs=[gmaxs[i] for i in rnd])
                     for i, o in zip(rnd, got):
                         xs[i].grad = o
                 todo = rest

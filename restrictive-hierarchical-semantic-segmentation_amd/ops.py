@@ -68,10 +68,11 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0):
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None):
+    """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h"""
     B, Hi, Wi, Cin = x_shape
     return ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
-                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec)
+                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec, grad_absmax=ptr(gmax))
 
 
 # ------------------------------------------------------------------ convolution
@@ -87,22 +88,22 @@ def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
     return out
 
 
-def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0):
+def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=None):
     """wt = weight_transpose(w): [Cin][k*k][Cout]."""
     B, Hi, Wi, Cin = x_shape
     if out is None:
         out = empty_nhwc(B, Hi, Wi, Cin, dy)
         accumulate = False
-    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s, prec)
+    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s, prec, gmax)
     call("hrseg_conv_dgrad", ptr(dy), ptr(wt), ptr(out), int(accumulate), C.byref(sh))
     return out
 
 
-def conv_wgrad(x, dy, dw, k, s, prec=0):
+def conv_wgrad(x, dy, dw, k, s, prec=0, gmax=None):
     """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
     if prec and k == 3 and s == 1:
-        return conv_wgrad_group([x], [dy], [dw], k, s, prec)
-    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec)
+        return conv_wgrad_group([x], [dy], [dw], k, s, prec, [gmax])
+    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, gmax)
     call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
 
 
@@ -124,21 +125,22 @@ def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
     return outs
 
 
-def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0):
+def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=None):
     """outs[i] None -> allocated (accumulate ignored)"""
     outs, acc, shapes = list(outs), list(accumulate), []
     for i, (dy, xs) in enumerate(zip(dys, x_shapes)):
         if outs[i] is None:
             outs[i] = empty_nhwc(xs[0], xs[1], xs[2], xs[3], dy)
             acc[i] = False
-        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s, prec))
+        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s, prec, gmaxs[i] if gmaxs is not None else None))
     call("hrseg_conv_dgrad_group", len(dys), _lib.ptr_array(dys), _lib.ptr_array(wts), _lib.ptr_array(outs),
          _lib.int_array([int(a) for a in acc]), _shape_array(shapes))
     return outs
 
 
-def conv_wgrad_group(xs, dys, dws, k, s, prec=0):
-    shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec) for x, dy in zip(xs, dys)])
+def conv_wgrad_group(xs, dys, dws, k, s, prec=0, gmaxs=None):
+    gm = gmaxs if gmaxs is not None else [None] * len(xs)
+    shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, g) for x, dy, g in zip(xs, dys, gm)])
     nbytes = _lib.conv_wgrad_workspace_bytes(shapes) if (prec and k == 3 and s == 1) else 0
     if nbytes:
         # split-precision 3x3 stride-1 problems: per-block partial sums in a workspace + ordered reduce (no atomics)
@@ -269,6 +271,7 @@ def bn_bwd_group(items, eval_mode):
         a.dres, a.lddres = ptr(dres), (_ld(dres) if dres is not None else 0)
         a.dres_accumulate = int(bool(it.get("dres_accumulate", False)))
         a.npix, a.C, a.partial, a.nchunks = npix, Cn, ptr(part), nch
+        a.dy_absmax = ptr(it.get("dy_absmax"))
     call("hrseg_bn_bwd_group", n, arr, int(eval_mode))
     return [it["dz"] for it in items]
 

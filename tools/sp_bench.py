@@ -20,7 +20,8 @@ SHAPES = [  # name, Cin, Cout, k, s, H, W
 ]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 only = sys.argv[2] if len(sys.argv) > 2 else None
-MODES = [m for m in os.environ.get("SP_MODES", "f32,bf16x3,bf16x2,bf16").split(",")]
+MODES = [m for m in os.environ.get("SP_MODES", "f32,bf16x3,fp16x2,bf16x2,bf16").split(",")]
+DYSCALE = float(os.environ.get("SP_DYSCALE", "1"))       # magnitude of the gradient operand (fp16x2 scales by its |max|)
 WHAT = os.environ.get("SP_WHAT", "fwd,dgrad,wgrad").split(",")
 
 
@@ -49,13 +50,15 @@ for name, ci, co, k, s, H, W in SHAPES:
     x = torch.randn(B, H, W, ci, device="cuda", generator=g)
     w = torch.randn(co, k * k, ci, device="cuda", generator=g) * 0.05
     y0 = ops.conv_fwd(x, w, None, k, s)
-    dy = torch.randn(y0.shape, device="cuda", generator=g)
+    dy = torch.randn(y0.shape, device="cuda", generator=g) * DYSCALE
+    gmax_t = dy.abs().max().reshape(1).repeat(64)
     wt = ops.weight_transpose(w, co, k * k, ci)
     flops = 2.0 * y0.numel() * ci * k * k
     ref = {}
     line = "%-22s %6.1f GF |" % (name, flops / 1e9)
     for mode in MODES:
         pr = _lib.CONV_PRECISION[mode]
+        gm = gmax_t if mode == "fp16x2" else None
         out = []
         if "fwd" in WHAT:
             y = ops.conv_fwd(x, w, None, k, s, prec=pr)
@@ -63,15 +66,15 @@ for name, ci, co, k, s, H, W in SHAPES:
             ref.setdefault("fwd", y.clone())
             out.append("fwd %6.1f us %5.0f TF e=%.1e" % (t * 1e6, flops / t / 1e12, err(y, ref["fwd"])))
         if "dgrad" in WHAT:
-            dx = ops.conv_dgrad(dy, wt, x.shape, k, s, prec=pr)
-            t = timeit(lambda: ops.conv_dgrad(dy, wt, x.shape, k, s, out=dx, prec=pr))
+            dx = ops.conv_dgrad(dy, wt, x.shape, k, s, prec=pr, gmax=gm)
+            t = timeit(lambda: ops.conv_dgrad(dy, wt, x.shape, k, s, out=dx, prec=pr, gmax=gm))
             ref.setdefault("dgrad", dx.clone())
             out.append("dgrad %6.1f us %5.0f TF e=%.1e" % (t * 1e6, flops / t / 1e12, err(dx, ref["dgrad"])))
         if "wgrad" in WHAT:
             dw = torch.zeros_like(w)
-            ops.conv_wgrad(x, dy, dw, k, s, prec=pr)
+            ops.conv_wgrad(x, dy, dw, k, s, prec=pr, gmax=gm)
             dw1 = dw.clone()
-            t = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s, prec=pr))
+            t = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s, prec=pr, gmax=gm))
             ref.setdefault("wgrad", dw1)
             out.append("wgrad %6.1f us %5.0f TF e=%.1e" % (t * 1e6, flops / t / 1e12, err(dw1, ref["wgrad"])))
         print(line + " %-7s " % mode + " | ".join(out), flush=True)
@@ -91,6 +94,7 @@ if not only or "group" in only:
             e = max(err(a, b) for a, b in zip(ys, base))
             t = timeit(lambda: ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n], prec=pr))
             dws = [torch.zeros_like(w) for w in ws[:n]]
-            tw = timeit(lambda: ops.conv_wgrad_group(xs[:n], dys[:n], dws, 3, 1, prec=pr))
+            gms = [d.abs().max().reshape(1).repeat(64) for d in dys[:n]] if mode == "fp16x2" else None
+            tw = timeit(lambda: ops.conv_wgrad_group(xs[:n], dys[:n], dws, 3, 1, prec=pr, gmaxs=gms))
             print("group of %d branch convs  %-7s fwd %7.1f us %5.0f TF e=%.1e | wgrad %7.1f us %5.0f TF" % (
                 n, mode, t * 1e6, sum(fl[:n]) / t / 1e12, e, tw * 1e6, sum(fl[:n]) / tw / 1e12), flush=True)
