@@ -24,7 +24,7 @@ from ..engine import Act, FlatParams, Recorder
 from ..utils.hierarchy import build_hierarchy_indices, child_groups, get_level_classes  # noqa: F401 (API)
 
 BN_MOMENTUM = 0.1
-DEFAULT_CONV_DTYPE = "f32"
+DEFAULT_CONV_DTYPE = "auto"
 
 
 # ----------------------------------------------------------------------------- parameter holders

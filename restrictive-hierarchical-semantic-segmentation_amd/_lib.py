@@ -122,9 +122,9 @@ _lib.hrseg_conv_wgrad_workspace_bytes.restype = C.c_size_t
 _lib.hrseg_conv_wgrad_workspace_bytes.argtypes = [_i, C.POINTER(ConvShape)]
 
 
-def conv_wgrad_workspace_bytes(shapes):
+def conv_wgrad_workspace_bytes(shapes, n=None):
     """bytes of workspace the nine-tap weight-gradient path wants for these problems (0: not applicable)"""
-    return int(_lib.hrseg_conv_wgrad_workspace_bytes(len(shapes), shapes))
+    return int(_lib.hrseg_conv_wgrad_workspace_bytes(len(shapes) if n is None else n, shapes))
 
 
 _lib.hrseg_tune.restype = _i

@@ -502,23 +502,25 @@ static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
 
 static int sp_pieces(int precision) {    // hrseg_conv_precision -> split scheme of conv_sp.h (0: the fp32 MFMA kernels)
   return precision == HRSEG_CONV_BF16X3 ? 3 : precision == HRSEG_CONV_BF16X2 ? 2 : precision == HRSEG_CONV_BF16 ? 1
-       : precision == HRSEG_CONV_FP16X2 ? 4 : 0;
+       : precision == HRSEG_CONV_FP16X2 ? 4 : 0;      // AUTO is resolved per problem before this is asked
 }
 // fp16x2: weights are scaled by a fixed 2^8 before the split (|w| up to 255 stays in fp16 range, typical
 // |w| ~ 0.01-1 keeps its low piece out of the subnormals)
+static bool is_f16(int precision) { return precision == HRSEG_CONV_FP16X2 || precision == HRSEG_CONV_AUTO; }
 static void set_sp_scales(IgemmArgs& a, int precision, const float* grad_absmax) {
-  const bool f16 = precision == HRSEG_CONV_FP16X2;
+  const bool f16 = is_f16(precision);
   a.wscale = f16 ? 256.f : 1.f;
   a.wscale_inv = f16 ? 1.f / 256.f : 1.f;
   a.xmax = f16 ? grad_absmax : nullptr;
 }
 
 // HRSEG_CONV_AUTO: fp32-grade results from whichever kernel family is faster for the problem (measured on
-// MI355X, tools/sp_bench.py): the bf16x3 kernels for problems of at least 8192 output pixels (the halo-patch
-// body on wide 3x3 stride-1 images, the im2col body otherwise), the fp32 MFMA kernels for the small ones
+// MI355X, tools/sp_bench.py): forward / data gradient: the fp16x2 kernels for problems of at least 8192 output
+// pixels (the halo-patch body on wide 3x3 stride-1 images, the im2col body otherwise), the fp32 MFMA kernels for
+// the small ones; weight gradients: fp16x2 throughout
 static int resolve_auto(const IgemmArgs& a, int precision) {
   if (precision != HRSEG_CONV_AUTO) return precision;
-  return a.M >= 8192 ? HRSEG_CONV_BF16X3 : HRSEG_CONV_F32;
+  return a.M >= 8192 ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
 }
 
 static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
@@ -588,8 +590,9 @@ static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, int cs, hipStr
 }
 
 static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st);
-// HRSEG_CONV_AUTO on a group: the problems the halo-patch body takes go out as one bf16x3 launch, the rest as
-// one fp32 launch (a low-resolution branch inside a patch launch would run at the patch body's occupancy)
+// HRSEG_CONV_AUTO on a group: the problems the halo-patch body takes go out as one fp16x2 launch (a
+// low-resolution branch inside a patch launch would run at the patch body's occupancy); of the rest, the small ones
+// (< 8192 pixels) as one fp32 launch and the others one by one
 static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st) {
   IgemmArgs hi[MAXG], lo[MAXG];
   int nh = 0, nl = 0;
@@ -600,15 +603,26 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st) 
     if (wtn && patch_cs(f, wtn) == wtn) hi[nh++] = a[i];
     else lo[nl++] = a[i];
   }
-  if (nh == 0) return dispatch_igemm_group(a, n, HRSEG_CONV_F32, st);
-  int rc = (nh >= 2) ? dispatch_igemm_group(hi, nh, HRSEG_CONV_BF16X3, st) : 1;
+  if (nh == 0) {
+    bool small = true, large = true;
+    for (int i = 0; i < n; ++i) { small = small && a[i].M < 8192; large = large && a[i].M >= 8192; }
+    if (small) return dispatch_igemm_group(a, n, HRSEG_CONV_F32, st);
+    if (large) return dispatch_igemm_group(a, n, HRSEG_CONV_FP16X2, st);
+  }
+  int rc = (nh >= 2) ? dispatch_igemm_group(hi, nh, HRSEG_CONV_FP16X2, st) : 1;
   if (rc != 0)
     for (int i = 0; i < nh; ++i)
-      if (int e = dispatch_igemm(hi[i], HRSEG_CONV_BF16X3, st)) return e < 0 ? e : 1;
-  rc = (nl >= 2) ? dispatch_igemm_group(lo, nl, HRSEG_CONV_F32, st) : 1;
+      if (int e = dispatch_igemm(hi[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : 1;
+  IgemmArgs sm[MAXG];
+  int nsm = 0;
+  for (int i = 0; i < nl; ++i) {
+    if (lo[i].M < 8192) { sm[nsm++] = lo[i]; continue; }
+    if (int e = dispatch_igemm(lo[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : 1;
+  }
+  rc = (nsm >= 2) ? dispatch_igemm_group(sm, nsm, HRSEG_CONV_F32, st) : 1;
   if (rc != 0)
-    for (int i = 0; i < nl; ++i)
-      if (int e = dispatch_igemm(lo[i], HRSEG_CONV_AUTO, st)) return e < 0 ? e : 1;
+    for (int i = 0; i < nsm; ++i)
+      if (int e = dispatch_igemm(sm[i], HRSEG_CONV_F32, st)) return e < 0 ? e : 1;
   return 0;
 }
 
@@ -1276,6 +1290,14 @@ static bool mfma_shape(const hrseg_conv_shape_t* s) {
   return s->Cin % 16 == 0 && s->Cout % 16 == 0 && s->ldx % 4 == 0 && s->ldy % 4 == 0;
 }
 
+// weight gradients under AUTO run fp16x2 (faster than the fp32 kernels on every measured shape)
+static void resolve_wgrad_shapes(int n, const hrseg_conv_shape_t* in, hrseg_conv_shape_t* out) {
+  for (int i = 0; i < n; ++i) {
+    out[i] = in[i];
+    if (out[i].precision == HRSEG_CONV_AUTO) out[i].precision = HRSEG_CONV_FP16X2;
+  }
+}
+
 // ---- grouped entry points: n independent problems, one launch when they can share a kernel
 extern "C" int hrseg_conv_fwd_group(int n, const float* const* x, const float* const* w, const float* const* bias,
                                     float* const* y, const hrseg_conv_shape_t* shapes, hrseg_stream_t stream) {
@@ -1344,17 +1366,22 @@ extern "C" int hrseg_conv_wgrad_group(int n, const float* const* x, const float*
   return 0;
 }
 
-extern "C" size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes) {
-  if (!shapes) return 0;
+extern "C" size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes_in) {
+  if (!shapes_in || n < 1 || n > WG9_MAXG) return 0;
+  hrseg_conv_shape_t shapes[WG9_MAXG];
+  resolve_wgrad_shapes(n, shapes_in, shapes);
   for (int i = 0; i < n; ++i)
     if (check_shape(&shapes[i], "hrseg_conv_wgrad_workspace_bytes")) return 0;
   return wgrad9_ws_bytes(n, shapes);
 }
 
 extern "C" int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
-                                         const hrseg_conv_shape_t* shapes, void* workspace, size_t workspace_bytes,
+                                         const hrseg_conv_shape_t* shapes_in, void* workspace, size_t workspace_bytes,
                                          hrseg_stream_t stream) {
-  HRSEG_CHECK_ARG(n >= 1 && x && dy && dw && shapes, "hrseg_conv_wgrad_group_ws: bad arguments");
+  HRSEG_CHECK_ARG(n >= 1 && x && dy && dw && shapes_in, "hrseg_conv_wgrad_group_ws: bad arguments");
+  if (n > WG9_MAXG) return hrseg_conv_wgrad_group(n, x, dy, dw, shapes_in, stream);
+  hrseg_conv_shape_t shapes[WG9_MAXG];
+  resolve_wgrad_shapes(n, shapes_in, shapes);
   for (int i = 0; i < n; ++i)
     if (int e = check_shape(&shapes[i], "hrseg_conv_wgrad_group_ws")) return e;
   const size_t need = wgrad9_ws_bytes(n, shapes);
@@ -1458,8 +1485,12 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
   return 0;
 }
 
-extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s,
+extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s_in,
                                 hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(s_in != nullptr, "hrseg_conv_wgrad: null shape");
+  hrseg_conv_shape_t sh;
+  resolve_wgrad_shapes(1, s_in, &sh);
+  const hrseg_conv_shape_t* s = &sh;
   if (int e = check_shape(s, "hrseg_conv_wgrad")) return e;
   HRSEG_CHECK_ARG(x && dy && dw, "hrseg_conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;

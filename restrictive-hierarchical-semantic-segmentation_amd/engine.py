@@ -240,7 +240,7 @@ class Recorder:
         coefs = [c for _, c in zc]
         eval_mode = not self.training
 
-        want_gmax = self.prec == _lib.CONV_PRECISION["fp16x2"]
+        want_gmax = self.prec in (_lib.CONV_PRECISION["fp16x2"], _lib.CONV_PRECISION["auto"])
 
         def bwd():
             bw = []

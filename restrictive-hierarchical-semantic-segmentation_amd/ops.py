@@ -141,7 +141,7 @@ def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=N
 def conv_wgrad_group(xs, dys, dws, k, s, prec=0, gmaxs=None):
     gm = gmaxs if gmaxs is not None else [None] * len(xs)
     shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, g) for x, dy, g in zip(xs, dys, gm)])
-    nbytes = _lib.conv_wgrad_workspace_bytes(shapes) if (prec and k == 3 and s == 1) else 0
+    nbytes = _lib.conv_wgrad_workspace_bytes(shapes, len(xs)) if (prec and k == 3 and s == 1) else 0
     if nbytes:
         # split-precision 3x3 stride-1 problems: per-block partial sums in a workspace + ordered reduce (no atomics)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=xs[0].device)
