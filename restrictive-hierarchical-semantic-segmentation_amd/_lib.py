@@ -226,5 +226,12 @@ def require_gpu():
                            "(the CPU oracle under oracle/ is test infrastructure, not a fallback)")
 
 
+def set_deterministic(on=True):
+    """bit-reproducible gradients: every float reduction takes its single-adder form (see csrc/common.h)"""
+    tune(deterministic=int(bool(on)))
+
+
+if os.environ.get("HRSEG_DETERMINISTIC", "0") == "1":
+    set_deterministic(True)
 if "HRSEG_TUNE" in os.environ:               # "key=value,key=value" A/B switch for tuning runs
     tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["HRSEG_TUNE"].split(",") if kv})

@@ -11,6 +11,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HRSEG_WAVE 64
 
 void hrseg_set_error(const char* fmt, ...);
+// hrseg_tune("deterministic", 1): every reduction that would add floats with atomics in a run-dependent order
+// takes its single-adder form instead (no split-K, one pixel range per weight-gradient tile, one block per image
+// in the head / loss reductions): bit-reproducible gradients at some cost in speed
+extern int hrseg_g_deterministic;
 
 #define HRSEG_CHECK_ARG(cond, ...)            \
   do {                                        \

@@ -379,6 +379,7 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
   if (g_tune_kc && a.K % (16 * g_tune_kc) == 0) pl.kc = g_tune_kc;
   if (g_tune_db) pl.db = g_tune_db;
   if (g_tune_ksplit) pl.ksplit = g_tune_ksplit;
+  if (hrseg_g_deterministic) pl.ksplit = 1;
   // split-K needs an output it may add into: accumulate mode, or a contiguous tensor it can zero
   const int nst = a.ntaps * (a.K / (16 * pl.kc));
   if (pl.ksplit > nst) pl.ksplit = nst;
@@ -429,6 +430,7 @@ static SpPlan plan_sp(const IgemmArgs& a) {
     if (pl.ksplit > nslabs / 8) pl.ksplit = nslabs / 8;
   }
   if (g_sp_ksplit) pl.ksplit = g_sp_ksplit;
+  if (hrseg_g_deterministic) pl.ksplit = 1;
   if (pl.ksplit > nslabs) pl.ksplit = nslabs;
   if (pl.ksplit < 1) pl.ksplit = 1;
   if (!(a.accumulate || (a.ldy == a.N && a.oys == 1 && a.oxs == 1))) pl.ksplit = 1;
@@ -663,7 +665,7 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     const int nstages = ns ? (a[i].ntaps * (a[i].K / 16) + 1) / 2 : a[i].ntaps * (a[i].K / (16 * kc));
     ks[i] = 1;
     const bool can_split = !kind[i] && (a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1));
-    if (can_split && tiles[i] < 512) {
+    if (can_split && tiles[i] < 512 && !hrseg_g_deterministic) {
       ks[i] = ceil_div(512, tiles[i]);
       const int min_stages = ns ? 8 : 12;        // stages (fp32: 16*kc channels; split precision: 32-channel slabs) per slice
       if (ks[i] > nstages / min_stages) ks[i] = nstages / min_stages;
@@ -1009,7 +1011,7 @@ template <int TN, int TK, int PIX, int DB>
 static int launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
   const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
   int ksplit = target_blocks / tiles;
-  if (ksplit < 1) ksplit = 1;
+  if (ksplit < 1 || hrseg_g_deterministic) ksplit = 1;       // deterministic: one pixel range, one adder per element
   int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
   if (ppb < 4 * PIX) ppb = 4 * PIX;
   a.pix_per_block = ppb;
@@ -1045,7 +1047,7 @@ static int launch_wgrad_sp(WgradArgs a, hipStream_t st) {
   if (target > 4096) target = 4096;
   if (g_tune_wg_blocks) target = g_tune_wg_blocks;
   int ksplit = target / tiles;
-  if (ksplit < 1) ksplit = 1;
+  if (ksplit < 1 || hrseg_g_deterministic) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
   if (ppb < 2 * PIX) ppb = 2 * PIX;
   a.pix_per_block = ppb;
@@ -1076,7 +1078,7 @@ static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, in
   if (target < tmin) target = tmin;
   if (target > tmax) target = tmax;
   int ksplit = target / tiles;
-  if (ksplit < 1) ksplit = 1;
+  if (ksplit < 1 || hrseg_g_deterministic) ksplit = 1;
   int ppb = ceil_div(ceil_div(a.M, ksplit), pix) * pix;
   if (ppb < 4 * pix) ppb = 4 * pix;
   a.pix_per_block = ppb;
@@ -1499,7 +1501,7 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
     const long M = (long)s->B * s->Ho * s->Wo;
     // ~512 blocks (measured, tools/misc_bench.py): every block adds into the same Cout*T*Cin
     // addresses, ~0.35 us of serialized atomics per block; fewer blocks leave CUs idle
-    const int nblk_target = g_tune_wg_blocks ? g_tune_wg_blocks : 512;
+    const int nblk_target = hrseg_g_deterministic ? 1 : g_tune_wg_blocks ? g_tune_wg_blocks : 512;
     int ppb = (int)ceil_div(ceil_div(M, nblk_target), 64) * 64;
     dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
     hipLaunchKernelGGL(conv_small_cin_wgrad_kernel, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi,
@@ -1563,7 +1565,8 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}};
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
+      {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)
     if (!strcmp(e.k, key)) { *e.v = value; return 0; }

@@ -5,6 +5,7 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+int hrseg_g_deterministic = 0;
 
 void hrseg_set_error(const char* fmt, ...) {
   va_list ap;

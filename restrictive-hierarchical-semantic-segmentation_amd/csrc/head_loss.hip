@@ -150,13 +150,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ df, int lddf, int df_acc,
                                                        float* __restrict__ dw, float* __restrict__ dbias,
                                                        float* __restrict__ dgb, long hw, int F, int Cout,
-                                                       long pix_per_block) {
+                                                       long pix_per_block, int b0) {
   __shared__ float red[256];
   const int Q = F >> 2;
   const int P = (Q >= 256) ? 1 : 256 / Q;
   const int cq = threadIdx.x % Q, pl = threadIdx.x / Q;
   const bool active = pl < P;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y + b0;
   const long lo = (long)blockIdx.x * pix_per_block;
   const long hi = (lo + pix_per_block < hw) ? lo + pix_per_block : hw;
   f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f};
@@ -750,13 +750,18 @@ extern "C" int hrseg_head_bwd(const float* f, int ldf, const float* gb, const fl
   if (chunks < 1) chunks = 1;
   long ppb = (hw + chunks - 1) / chunks;
   if (ppb < 64) ppb = 64;
-  dim3 grid(ceil_div(hw, ppb), B);
-  if (Cout <= 4)
-    hipLaunchKernelGGL((head_bwd_kernel<4>), grid, dim3(256), 0, st, f, ldf, gb, w, dz, lddz, df, lddf, df_accumulate,
-                       dw, dbias, dgb, hw, F, Cout, ppb);
-  else
-    hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, st, f, ldf, gb, w, dz, lddz, df, lddf, df_accumulate,
-                       dw, dbias, dgb, hw, F, Cout, ppb);
+  // deterministic: one block per image, the images one launch after the other (a single adder per dW element at a time)
+  const int nlaunch = hrseg_g_deterministic ? B : 1;
+  if (hrseg_g_deterministic) ppb = hw;
+  dim3 grid(ceil_div(hw, ppb), hrseg_g_deterministic ? 1 : B);
+  for (int b0 = 0; b0 < nlaunch; ++b0) {
+    if (Cout <= 4)
+      hipLaunchKernelGGL((head_bwd_kernel<4>), grid, dim3(256), 0, st, f, ldf, gb, w, dz, lddz, df, lddf, df_accumulate,
+                         dw, dbias, dgb, hw, F, Cout, ppb, b0);
+    else
+      hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, st, f, ldf, gb, w, dz, lddz, df, lddf, df_accumulate,
+                         dw, dbias, dgb, hw, F, Cout, ppb, b0);
+  }
   HRSEG_LAUNCH_CHECK("head_bwd");
   return 0;
 }
@@ -840,7 +845,7 @@ extern "C" int hrseg_loss_partials(const float* z, const float* t, double* parti
   HRSEG_CHECK_ARG(z && t && partial && B > 0 && C > 0 && C <= MAXC && hw > 0, "hrseg_loss_partials: bad arguments (C=%d)", C);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(256), 0, st, partial, B * C * 5);   // kernel node, not memset
-  long chunks = 1024 / B;
+  long chunks = hrseg_g_deterministic ? 1 : 1024 / B;      // deterministic: one block (one adder) per image
   if (chunks < 1) chunks = 1;
   long ppb = (hw + chunks - 1) / chunks;
   if (ppb < 256) ppb = 256;
@@ -881,6 +886,7 @@ extern "C" int hrseg_consistency(const float* p, const float* pprev, double* out
   const long n = (long)B * hw;
   long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
+  if (hrseg_g_deterministic) blocks = 1;
   hipLaunchKernelGGL(consistency_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, pprev, out, C, Cprev,
                      hw, n, g);
   HRSEG_LAUNCH_CHECK("consistency");

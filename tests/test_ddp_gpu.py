@@ -47,9 +47,10 @@ def _local_grad(name, shard):
     return model._flat.grad.clone()
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, deterministic):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HRSEG_WGRAD_STREAM="0")           # two processes time-slice one card: keep one stream each
+                      HRSEG_WGRAD_STREAM="0",           # two processes time-slice one card: keep one stream each
+                      HRSEG_DETERMINISTIC="1" if deterministic else "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hrseg_amd import train as PT
     from hrseg_amd.parallel import GradSync
@@ -69,10 +70,20 @@ def _worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
 @pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64"])
-def test_two_rank_step_sums_gradients_and_keeps_replicas_identical(name, tmp_path):
-    port = 29600 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+def test_two_rank_step_sums_gradients_and_keeps_replicas_identical(name, deterministic, tmp_path):
+    from hrseg_amd import _lib
+    port = 29600 + (os.getpid() % 300) + (300 if deterministic else 0)
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path), deterministic), nprocs=2, join=True)
+    _lib.set_deterministic(deterministic)
+    try:
+        _check(name, tmp_path, deterministic)
+    finally:
+        _lib.set_deterministic(False)
+
+
+def _check(name, tmp_path, deterministic):
     g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
     d0, d1 = np.load(tmp_path / "data0.npy"), np.load(tmp_path / "data1.npy")
     assert np.array_equal(g0, g1), "all-reduced gradients differ between ranks"
@@ -81,6 +92,12 @@ def test_two_rank_step_sums_gradients_and_keeps_replicas_identical(name, tmp_pat
     again = (_local_grad(name, 0) + _local_grad(name, 1)).cpu().numpy()      # run-to-run noise of the fp32 atomics
     scale = np.abs(want).max()
     noise = np.abs(again - want).max() / scale
+    if deterministic:
+        # single-adder reductions everywhere: the local gradients reproduce bit for bit, and the all-reduced
+        # gradient is their fp32 sum
+        assert np.array_equal(again, want), "deterministic mode: two runs of the same shard differ"
+        assert np.abs(g0 - want).max() / scale < 1e-5, np.abs(g0 - want).max() / scale
+        return
     assert np.abs(g0 - want).max() / scale < max(2e-2, 4 * noise), (np.abs(g0 - want).max() / scale, noise)
     big = np.abs(want) > 1e-3 * scale
     med = np.median(np.abs(g0 - want)[big] / np.abs(want)[big])
