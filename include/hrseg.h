@@ -334,6 +334,15 @@ int hrseg_comm_destroy(void* comm);
 int hrseg_encode_targets(const unsigned char* label, const unsigned long long* on_lut, const int* parent,
                          float* out, int B, int C, long hw, hrseg_stream_t stream);
 
+/* ------------------------------------------------------------------ level synthesis for flat models (evaluation side)
+ * predictEval.py:85-129 get_parent_masks (parent = union of its descendant leaves, "any > 0") and :134-185
+ * combine_levels (per-level tensors stitched from leaf and parent channels).  out[b][o] is the COPY of the single
+ * input channel selected by masks[o] (is_union[o] == 0) or 1.0 where any selected input channel is > 0, else 0.0.
+ * Input channel i < C0 is plane i of x0, else plane i - C0 of x1 (x1 may be NULL with C1 == 0).  NCHW planes;
+ * masks / is_union are HOST arrays of Cout entries; C0 + C1 <= 64, Cout <= 64. */
+int hrseg_combine_levels(const float* x0, int C0, const float* x1, int C1, const unsigned long long* masks,
+                         const int* is_union, float* out, int B, int Cout, long hw, hrseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "hrseg_adamw_dev": [_p, _p, _p, _p, _l, _p, _p, _p],
     "hrseg_fill": [_p, _f, _l, _p],
     "hrseg_encode_targets": [_p, _p, C.POINTER(C.c_int), _p, _i, _i, _l, _p],
+    "hrseg_combine_levels": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _l, _p],
 }
 # entry points without the trailing stream argument convention of `call`
 RAW_PROTOTYPES = {

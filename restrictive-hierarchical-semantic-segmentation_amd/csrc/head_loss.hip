@@ -971,3 +971,50 @@ extern "C" int hrseg_encode_targets(const unsigned char* label, const unsigned l
   HRSEG_LAUNCH_CHECK("encode_targets");
   return 0;
 }
+
+// --------------------------------------------------------------------------- level synthesis for flat models
+// predictEval.py:85-185 (get_parent_masks / combine_levels): out[b][o][pix] is, per output channel o, either the COPY
+// of one input channel (mask with a single bit) or the UNION "any selected channel > 0" (1.0 / 0.0) of the input
+// channels whose bits are set.  Input channel i < C0 is plane i of x0, else plane i - C0 of x1 (the leaves and the
+// already synthesised parents of combine_levels).  One thread per pixel, planes coalesced.
+struct LevelTable { unsigned long long mask[64]; int is_union[64]; };
+__global__ __launch_bounds__(256) void combine_levels_kernel(const float* __restrict__ x0, int C0,
+                                                             const float* __restrict__ x1, int C1,
+                                                             float* __restrict__ out, int Cout, long hw, long n,
+                                                             LevelTable tab) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / hw, pix = i - b * hw;
+    for (int o = 0; o < Cout; ++o) {
+      unsigned long long m = tab.mask[o];
+      float v = 0.f;
+      while (m) {
+        const int c = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float xv = (c < C0) ? x0[((size_t)b * C0 + c) * hw + pix] : x1[((size_t)b * C1 + (c - C0)) * hw + pix];
+        if (tab.is_union[o]) v = (xv > 0.f) ? 1.f : v;
+        else v = xv;
+      }
+      out[((size_t)b * Cout + o) * hw + pix] = v;
+    }
+  }
+}
+
+extern "C" int hrseg_combine_levels(const float* x0, int C0, const float* x1, int C1, const unsigned long long* masks,
+                                    const int* is_union, float* out, int B, int Cout, long hw, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(x0 && masks && is_union && out && B > 0 && hw > 0 && C0 > 0 && C1 >= 0 && C0 + C1 <= 64 && Cout > 0 && Cout <= 64 &&
+                      (C1 == 0 || x1), "hrseg_combine_levels: bad arguments (C0=%d C1=%d Cout=%d)", C0, C1, Cout);
+  LevelTable tab;
+  for (int o = 0; o < Cout; ++o) {
+    HRSEG_CHECK_ARG(masks[o] != 0 && (C0 + C1 == 64 || (masks[o] >> (C0 + C1)) == 0),
+                    "hrseg_combine_levels: channel %d selects no input / an input beyond %d", o, C0 + C1);
+    tab.mask[o] = masks[o];
+    tab.is_union[o] = is_union[o];
+  }
+  const long n = (long)B * hw;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(combine_levels_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x0, C0, x1, C1, out, Cout,
+                     hw, n, tab);
+  HRSEG_LAUNCH_CHECK("combine_levels");
+  return 0;
+}

@@ -356,6 +356,21 @@ def encode_targets(label, on_lut, parent):
     return out
 
 
+def combine_levels(x0, x1, masks, is_union):
+    """x0 [B,C0,H,W] (+ x1 [B,C1,H,W] or None), per output channel a bit mask over the C0+C1 input channels and a
+    union flag -> [B,len(masks),H,W]: copy of the selected channel, or 1.0 where any selected channel is > 0"""
+    x0 = _c(x0.float())
+    B, C0, H, W = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = _c(x1.float())
+        C1 = x1.shape[1]
+    out = torch.empty((B, len(masks), H, W), dtype=torch.float32, device=x0.device)
+    call("hrseg_combine_levels", ptr(x0), C0, ptr(x1), C1, (C.c_ulonglong * len(masks))(*[int(m) for m in masks]),
+         _lib.int_array([int(u) for u in is_union]), ptr(out), B, len(masks), H * W)
+    return out
+
+
 def fill(t, v):
     call("hrseg_fill", ptr(t), float(v), t.numel())
     return t

@@ -1,0 +1,87 @@
+"""Evaluation side on the GPU: the flat-model level synthesis (predictEval.py:85-185) against the vectors the
+reference's own functions produced, and train.test() -- the reference's validation loop (train.py:282-393) --
+against the CPU oracle's eval pass on a golden case."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,tree_file", [("tl", "class_tree_tl.json"), ("ext", "class_tree_tl_extended.json")])
+def test_parent_masks_and_combine_levels_match_the_reference(tag, tree_file):
+    from hrseg_amd import predictEval as PE
+    tree = load_tree(tree_file)
+    g = load_golden("predict_eval")
+    ch = PE.children_map(tree)
+    leaves = [n for n in PE.bfs_order(tree) if not ch[n]]
+    parents = [n for n in PE.bfs_order(tree) if ch[n]]
+    li = {n: i for i, n in enumerate(leaves)}
+    X, Y = torch.from_numpy(g[f"{tag}_X"]).cuda(), torch.from_numpy(g[f"{tag}_Y"]).cuda()
+    px, py, names = PE.get_parent_masks([X], [Y], tree, li)
+    assert names == parents
+    assert np.array_equal(px[0].cpu().numpy(), g[f"{tag}_parents_X"]) and np.array_equal(py[0].cpu().numpy(), g[f"{tag}_parents_Y"])
+    lx = PE.combine_levels([X], px, tree, leaves, parents)
+    ly = PE.combine_levels([Y], py, tree, leaves, parents)
+    assert len(lx) == int(g[f"{tag}_nlevels"])
+    for L, (a, b) in enumerate(zip(lx, ly)):
+        assert np.array_equal(a.cpu().numpy(), g[f"{tag}_level{L}_X"]) and np.array_equal(b.cpu().numpy(), g[f"{tag}_level{L}_Y"])
+    with pytest.raises(KeyError):
+        PE.get_parent_masks([X], [Y], tree, {k: v for k, v in li.items() if k != leaves[-1]})
+    with pytest.raises(IndexError):
+        PE.get_parent_masks([X[:, :-1]], [Y[:, :-1]], tree, li)
+    with pytest.raises(KeyError):
+        PE.combine_levels([X], px, tree, leaves[:-1], parents)
+
+
+@pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64"])
+def test_validation_loop_matches_the_oracle_eval_pass(name):
+    """train.test(): eval-mode forward, metrics on the model's probabilities against the raw ternary targets, CE +
+    Dice + consistency on the probabilities -- every returned scalar / vector against the oracle"""
+    from oracle import losses as OL
+    from oracle import metrics as OM
+    from oracle import models as OMod
+    from oracle.train_step import split_levels
+    from hrseg_amd import train as PT
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd.Metrics import performance_metrics as PP
+    from hrseg_amd.Models import models as PM
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    nc = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    x, target = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
+    args = argparse.Namespace(model_type=1, model_select=0 if kind == "unet" else 1, num_classes=nc, level_weights=weights,
+                              level0_pretrain_epochs=None, batch_size=batch)
+    # oracle eval pass (train.py:282-340 restated on the CPU port)
+    om = build_model(OMod, kind, hier, tree, size)
+    om.eval()
+    with torch.no_grad():
+        probs, logits = om(x, type=1) if kind == "unet" else om(x)
+    targets = split_levels(target, nc)
+    want = {k: np.concatenate([OM.level_metrics(p.numpy(), t.numpy(), child_classes=(L > 0))[k]
+                               for L, (p, t) in enumerate(zip(probs, targets))]) for k in OM.METRIC_NAMES}
+    loss, parts, cons = OL.get_loss(logits, targets, weights, probs_per_level=probs, levels=om.levels, parent_of=om.parent_of)
+    # product
+    pm = build_model(PM, kind, hier, tree, size).cuda()
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in nc]
+    mets = [PP.Accuracy(), PP.Jaccardindex(), PP.DiceScore(), PP.Precision(), PP.Recall()]
+    loader = [(x, target)]
+    res = PT.test(pm, torch.device("cuda"), loader, 1, *mets, args, None, fns, tree, None)
+    perf_mean, perf_std, cls, acc, iou, dice, prec, rec, level_loss, last_loss = res
+    assert abs(last_loss - float(loss)) < 1e-3 * abs(float(loss)), (last_loss, float(loss))
+    for c in range(sum(nc)):
+        for k in OM.METRIC_NAMES:
+            assert abs(float(cls[c][k]) - float(want[k][c])) < 2e-3, (c, k, float(cls[c][k]), float(want[k][c]))
+    assert abs(iou - float(want["iou"].mean())) < 2e-3 and abs(dice - float(want["dice"].mean())) < 2e-3
+    assert abs(prec - float(want["precision"].mean())) < 2e-3 and abs(rec - float(want["recall"].mean())) < 2e-3
+    assert abs(perf_mean - float(want["dice"][1:].mean())) < 2e-3 and perf_std == 0.0
+    want_levels = [(float(ce) + (float(d) if d is not None else 0.0)) / (1 * batch) for ce, d in parts]
+    assert len(level_loss) == len(want_levels)
+    for a, b in zip(level_loss, want_levels):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (level_loss, want_levels)
