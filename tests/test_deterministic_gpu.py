@@ -74,4 +74,10 @@ def test_level_pass_modes_agree_up_to_the_nets_conditioning(deterministic):
         worst = max(errs, key=errs.get)
         med = float(np.median(list(errs.values())))
         print(f"{mode} vs sequential: worst {errs[worst]:.2e} ({worst}), median {med:.2e}")
-        assert med < 3e-2 and errs[worst] < 0.3, (mode, med, worst, errs[worst])
+        if mode == "dedup":
+            # same kernels on the same problem sizes, only the head gradients are summed in another order
+            assert med < 1e-4 and errs[worst] < 1e-3, (mode, med, worst, errs[worst])
+        else:
+            # batched passes double every problem size: other tile plans and, under the default 'auto' arithmetic,
+            # another kernel family for some layers -- a different (equally valid) fp32-grade evaluation
+            assert med < 3e-2 and errs[worst] < 0.3, (mode, med, worst, errs[worst])
