@@ -1,0 +1,200 @@
+"""The split-precision convolution kernels (csrc/conv_sp.h) through the C ABI against a plain fp32 torch-CPU
+convolution, mode by mode, and the bf16-input / fp32-accumulate path of BASELINE.json configs[4] on the models.
+
+Tolerances (relative to the reference's max magnitude), stated per mode:
+  fp16x2, bf16x3 : 2e-5  -- fp32-grade: operands carry 22 / 24 significant bits, fp32 accumulation
+  bf16x2         : 2e-4  -- operand error 2^-16
+  bf16           : 3e-2  -- operands rounded to 8 significant bits (2^-9 each), fp32 accumulation
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp16x2": 2e-5, "bf16x3": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}
+
+# Cin, Cout, k, s, H, W, B -- halo-patch body (wide 3x3 stride 1, 48- and 64-channel K stages, two K stages, ragged
+# edges), im2col body (1x1, stride 2, narrow images, odd unit count), nine-tap and tap-per-block weight gradients
+SP_CASES = [
+    (48, 48, 3, 1, 64, 96, 4), (96, 96, 3, 1, 61, 83, 3), (64, 64, 3, 1, 70, 70, 3), (128, 64, 3, 1, 57, 66, 3),
+    (48, 96, 3, 2, 31, 31, 2), (64, 256, 1, 1, 33, 47, 2), (144, 48, 1, 1, 15, 15, 2), (192, 192, 3, 1, 13, 11, 2),
+    (48, 48, 3, 1, 9, 130, 2), (384, 48, 3, 1, 8, 8, 2),
+]
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+@pytest.mark.parametrize("mode", list(TOL))
+@pytest.mark.parametrize("case", SP_CASES)
+@pytest.mark.parametrize("dyscale", [1.0, 1e-8])
+def test_split_precision_conv_against_torch(case, mode, dyscale):
+    from hrseg_amd import _lib, ops
+    if dyscale != 1.0 and mode != "fp16x2":
+        pytest.skip("the gradient-magnitude sweep concerns the fp16x2 operand scaling only")
+    cin, cout, k, s, H, W, B = case
+    pr = _lib.CONV_PRECISION[mode]
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, stride=s, padding=(k - 1) // 2)
+    dy = torch.randn(y_ref.shape, generator=g) * dyscale
+    y_ref.backward(dy)
+    tol = TOL[mode]
+    xd, wd, dyd = _nhwc(x), w.permute(0, 2, 3, 1).contiguous().cuda(), _nhwc(dy)
+    gmax = dyd.abs().max().reshape(1).repeat(64) if mode == "fp16x2" else None     # what hrseg_bn_bwd_group records
+    y = ops.conv_fwd(xd, wd, bias.cuda(), k, s, prec=pr)
+    assert _rel(_nchw(y), y_ref) < tol
+    wt = ops.weight_transpose(wd, cout, k * k, cin)
+    dx = ops.conv_dgrad(dyd, wt, xd.shape, k, s, prec=pr, gmax=gmax)
+    assert _rel(_nchw(dx), xr.grad) < tol
+    ops.conv_dgrad(dyd, wt, xd.shape, k, s, out=dx, accumulate=True, prec=pr, gmax=gmax)
+    assert _rel(_nchw(dx), 2 * xr.grad) < tol
+    dw = torch.zeros_like(wd)
+    ops.conv_wgrad(xd, dyd, dw, k, s, prec=pr, gmax=gmax)
+    ops.conv_wgrad(xd, dyd, dw, k, s, prec=pr, gmax=gmax)                          # second call accumulates
+    assert _rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), 2 * wr.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x3", "auto"])
+def test_grouped_branch_convs_in_split_precision(mode):
+    """the four parallel HRNet branches as ONE grouped launch (forward, data gradient, weight gradient)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION[mode]
+    chans, sizes, B = [48, 96, 192, 384], [(80, 96), (40, 48), (20, 24), (10, 12)], 4
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randn(B, c, h, w_, generator=g) for c, (h, w_) in zip(chans, sizes)]
+    ws = [torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5 for c in chans]
+    dys = [torch.randn(B, c, h, w_, generator=g) * 1e-4 for c, (h, w_) in zip(chans, sizes)]
+    refs = []
+    for x, w, dy in zip(xs, ws, dys):
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = F.conv2d(xr, wr, padding=1)
+        y.backward(dy)
+        refs.append((y.detach(), xr.grad, wr.grad))
+    xd = [_nhwc(x) for x in xs]
+    wd = [w.permute(0, 2, 3, 1).contiguous().cuda() for w in ws]
+    dyd = [_nhwc(d) for d in dys]
+    gm = [d.abs().max().reshape(1).repeat(64) for d in dyd]
+    ys = ops.conv_fwd_group(xd, wd, [None] * 4, 3, 1, chans, prec=pr)
+    wts = [ops.weight_transpose(w, c, 9, c) for w, c in zip(wd, chans)]
+    dxs = ops.conv_dgrad_group(dyd, wts, [x.shape for x in xd], 3, 1, [None] * 4, [False] * 4, prec=pr, gmaxs=gm)
+    dws = [torch.zeros_like(w) for w in wd]
+    ops.conv_wgrad_group(xd, dyd, dws, 3, 1, prec=pr, gmaxs=gm)
+    for i, (y, dx, dw) in enumerate(refs):
+        assert _rel(_nchw(ys[i]), y) < 2e-5, i
+        assert _rel(_nchw(dxs[i]), dx) < 2e-5, i
+        c = chans[i]
+        assert _rel(dws[i].view(c, 3, 3, c).permute(0, 3, 1, 2), dw) < 4e-5, i
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: bf16-input convolutions
+# bf16 operands (2^-9 each) through ~300 conv+BN layers at 62x62, where the lowest branch is 2x2 pixels and BatchNorm
+# normalises over 8 samples: measured relative L2 error of the logits 0.10-0.31 (level 0 worst), max-norm error up to 0.47 on single pixels, loss within 0.1 %
+BF16_LOGIT_L2_TOL = 0.5
+BF16_ARGMAX_AGREEMENT = 0.85
+
+
+def test_bf16_convs_on_the_extended_tree_golden():
+    """hrnet_hier_ext_62 (4-level tree) with model.conv_dtype = 'bf16': BN, heads, loss and optimizer stay fp32; the
+    outputs track the fp32 reference within the stated bf16 tolerance and the loss within 2 %"""
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    import argparse
+    kind, hier, tree_file, size, batch = CASES["hrnet_hier_ext_62"]
+    g = load_golden("hrnet_hier_ext_62")
+    tree = load_tree(tree_file)
+    model = build_model(PM, kind, hier, tree, size).cuda()
+    model.conv_dtype = "bf16"
+    nc = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for(tree_file, hier)
+    args = argparse.Namespace(model_type=1, model_select=1, num_classes=nc, level_weights=weights,
+                              level0_pretrain_epochs=None, batch_size=batch)
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    model.train()
+    probs, logits = PT._model_call(model, x, args, tree)
+    errs, l2, agree = [], [], []
+    for L, z in enumerate(logits):
+        got, ref = z.detach().cpu().numpy().astype(np.float64), g[f"logits{L}"].astype(np.float64)
+        errs.append(rel_err(got, ref))
+        l2.append(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+        agree.append(float((got.argmax(1) == ref.argmax(1)).mean()))
+    print("bf16 logits: max-norm error", ["%.2e" % e for e in errs], "L2 error", ["%.2e" % e for e in l2],
+          "arg-max agreement", ["%.3f" % a for a in agree])
+    assert max(l2) < BF16_LOGIT_L2_TOL and min(agree) > BF16_ARGMAX_AGREEMENT, (l2, agree)
+    loss = 0.0
+    for L, (z, t) in enumerate(zip(logits, PT.split_targets(target, args))):
+        ce, dice = PL.fused_ce_dice(z, t, weights[L])[:2]
+        loss = loss + ce + dice
+    want = sum(float(g[f"ce{L}"]) + float(g[f"dice{L}"]) for L in range(len(nc)))
+    print("bf16 loss", float(loss), "fp32 reference", want)
+    assert abs(float(loss) - want) < 5e-2 * abs(want), (float(loss), want)
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+def test_configs4_geometry_step_properties_in_bf16():
+    """BASELINE.json configs[4]: hierarchical HRNet-W48 on class_tree_tl_extended.json (4 levels), 1024x1024, batch 4,
+    bf16-input convolutions: one full train step, checked through size-independent properties (composition sums,
+    pixel bookkeeping, finite loss and gradients, L running-stat updates, the step lowers the loss on its batch)"""
+    import argparse
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT, ops
+    from hrseg_amd.utils import synth
+    from hrseg_amd.utils.hierarchy import get_classes
+    tree = load_tree("class_tree_tl_extended.json")
+    nc = get_classes(tree, full=True)
+    assert nc == [2, 2, 4, 3]
+    S, B = 1024, 4
+    model = build_model(PM, "hrnet", True, tree, S).cuda()
+    model.conv_dtype = "bf16"
+    weights = level_weights_for("class_tree_tl_extended.json", True)
+    args = argparse.Namespace(model_type=1, model_select=1, num_classes=nc, level_weights=weights,
+                              level0_pretrain_epochs=None, batch_size=B)
+    x_np, t_np = synth.synthetic_batch(tree, B, S, seed=4, hierarchical=True)
+    x, target = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in nc]
+    opt = PT.FusedAdamW(model, lr=[1e-3])
+    model.train()
+    with torch.no_grad():
+        probs, logits = PT._model_call(model, x, args, tree)
+    assert [tuple(p.shape) for p in probs] == [(B, n, S, S) for n in nc]
+    # every group of children sums to its parent's probability (models.py:763-798)
+    for L in range(1, len(nc)):
+        o = 0
+        for pname, kids in model.child_groups[L - 1]:
+            pi = model.levels[L - 1].index(pname)
+            s = probs[L][:, o:o + len(kids)].sum(1)
+            assert float((s - probs[L - 1][:, pi]).abs().max()) < 1e-4, (L, pname)
+            o += len(kids)
+    for L, (z, t) in enumerate(zip(logits, PT.split_targets(target, args))):
+        _, cm = ops.predict_metrics(z, t, child=(L > 0), mask_pred=True)
+        assert int(cm.sum()) == B * S * S
+    losses = []
+    for _ in range(3):
+        loss, _ = PT.train_step(model, opt, x, target, fns, args, tree, [])
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    for n, b in model.named_buffers():
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == 4 * 4, n          # 4 level passes per forward (D1), four training-mode forwards
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    print("configs[4] geometry, bf16 convs: losses", losses, "peak mem %.1f GB" % (torch.cuda.max_memory_allocated() / 2**30))
