@@ -100,13 +100,7 @@ def build(args, device):
     return tree, model, ns, loss_fns, opt
 
 
-def probe_dominant_kernel(device, batch, size, conv_dtype="f32"):
-    """The kernel with the largest share of the step is igemm_group_kernel: the 3x3 convs of the
-    parallel HRNet branches (48/96/192/384 channels at size/4, /8, /16, /32), one grouped launch per
-    BasicBlock conv.  One backbone pass issues 8 two-branch, 32 three-branch and 24 four-branch
-    groups (stage 2/3/4; the data-gradient launches have the same shapes); that exact mix is timed
-    here with events on the launch stream.  Algorithmic FLOPs = sum over branches of 2*M*N*K."""
-    from hrseg_amd import ops
+def _branch_tensors(device, batch, size):
     s4 = ((size + 1) // 2 + 1) // 2
     sizes = [s4]
     for _ in range(3):
@@ -115,92 +109,127 @@ def probe_dominant_kernel(device, batch, size, conv_dtype="f32"):
     xs = [torch.randn(batch, h, h, c, device=device) for c, h in zip(chans, sizes)]
     ws = [torch.randn(c, 9, c, device=device) * 0.05 for c in chans]
     fl = [2.0 * batch * h * h * c * c * 9 for c, h in zip(chans, sizes)]
-    mix = [(2, 8), (3, 32), (4, 24)]
+    return sizes, chans, xs, ws, fl
 
-    def one_pass():
-        for n, reps in mix:
-            for _ in range(reps):
-                ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n])
-    one_pass()
+
+def _timed(fn, reps=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 3
+    fn()
     e0.record()
     for _ in range(reps):
-        one_pass()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    launches = sum(r for _, r in mix)
-    ms = e0.elapsed_time(e1) / (reps * launches)
-    flops = sum(sum(fl[:n]) * r for n, r in mix) / launches
-    ach = flops / (ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic("igemm_group_kernel<1, 3, 3, 1, true>")
-    return {"bound": "mfma", "kernel": "igemm_group_kernel<1,3,3,1,true> (3x3 branch convs 48/96/192/384 ch at %s, B=%d; "
-                                       "stage-2/3/4 mix of one backbone pass)" % ("/".join(str(h) for h in sizes), batch),
-            "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)",
-            "traffic_source": traffic_src, "avg_launch_us": round(ms * 1e3, 2), "flop_per_launch": flops}
+    return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def probe_secondary_kernels(device, batch, size, conv_dtype="f32"):
-    """The next two kernel families by time, measured the same way (events on the launch stream, algorithmic work
-    over the measured duration): the grouped weight gradient of the branch convs (MFMA-bound) and the grouped
-    BatchNorm forward + backward of the four branches (HBM-bound; algorithmic bytes per element: statistics 4,
-    apply 8, backward reduce 8, backward apply 12 -- no residual, ReLU mask recomputed from y)."""
-    from hrseg_amd import ops
-    s4 = ((size + 1) // 2 + 1) // 2
-    sizes = [s4]
-    for _ in range(3):
-        sizes.append((sizes[-1] + 1) // 2)
-    chans = [48, 96, 192, 384]
-    xs = [torch.randn(batch, h, h, c, device=device) for c, h in zip(chans, sizes)]
-    dys = [torch.randn(batch, h, h, c, device=device) for c, h in zip(chans, sizes)]
+def probe_dominant_kernel(device, batch, size, conv_dtype="auto"):
+    """The kernel with the largest share of the step.
+    conv_dtype 'auto' / 'fp16x2' (default): igemm_sp_pgroup_kernel<fp16x2>, the halo-patch launch of the two
+    high-resolution HRNet branches (3x3 convs, 48 ch at size/4 and 96 ch at size/8) -- every BasicBlock conv of stages
+    2-4 issues one forward and one data-gradient launch of it (64 + 64 per backbone pass).  Timed here with events on
+    the launch stream.  `achieved` = ALGORITHMIC FLOPs (2*M*N*K per branch) / launch time; every fp32-grade product
+    costs three fp16 MFMA products, so `peak` = dense fp16 MFMA peak / 3 and `frac` = executed MFMA rate / 2.5 PFLOP/s.
+    conv_dtype 'f32': igemm_group_kernel on v_mfma_f32_16x16x4_f32 (stage-2/3/4 forward mix), peak 157.3."""
+    from hrseg_amd import _lib, ops
+    sizes, chans, xs, ws, fl = _branch_tensors(device, batch, size)
+    if conv_dtype == "f32":
+        mix = [(2, 8), (3, 32), (4, 24)]
+
+        def one_pass():
+            for n, reps in mix:
+                for _ in range(reps):
+                    ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n])
+        launches = sum(r for _, r in mix)
+        t = _timed(one_pass, 3) / launches
+        flops = sum(sum(fl[:n]) * r for n, r in mix) / launches
+        ach = flops / t / 1e12
+        traffic, src = pmc_value("igemm_group_kernel<1, 3, 3, 1, true>", "traffic")
+        return {"bound": "mfma", "kernel": "igemm_group_kernel<1,3,3,1,true> (3x3 branch convs 48/96/192/384 ch at %s, B=%d; "
+                                           "stage-2/3/4 mix of one backbone pass)" % ("/".join(str(h) for h in sizes), batch),
+                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)",
+                "traffic_source": src, "avg_launch_us": round(t * 1e6, 2), "flop_per_launch": flops}
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    t = _timed(lambda: ops.conv_fwd_group(xs[:2], ws[:2], [None, None], 3, 1, chans[:2], prec=pr), 50)
+    flops = fl[0] + fl[1]
+    ach = flops / t / 1e12
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+    name = "igemm_sp_pgroup_kernel<4, 2, 3, 3, 0>"
+    traffic, src = pmc_value(name, "traffic")
+    busy, bsrc = pmc_value(name, "mfma_busy")
+    return {"bound": "mfma",
+            "kernel": "igemm_sp_pgroup_kernel<fp16x2> (halo-patch 3x3 convs of the two high-resolution branches: 48 ch at %d, "
+                      "96 ch at %d, B=%d; forward launch, the data gradient runs the same kernel)" % (sizes[0], sizes[1], batch),
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMA products per fp32-grade product (fp16x2 split)",
+            "executed_mfma_tflops": round(3 * ach, 1), "algorithmic_vs_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 3),
+            "mfma_busy": busy, "mfma_busy_source": bsrc,
+            "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)", "traffic_source": src,
+            "avg_launch_us": round(t * 1e6, 2), "flop_per_launch": flops}
+
+
+def probe_secondary_kernels(device, batch, size, conv_dtype="auto"):
+    """The next kernel families by time, measured the same way (events on the launch stream, algorithmic work over the
+    measured duration): the grouped weight gradient of the four branch convs (auto: wgrad9_sp_group_kernel3<fp16x2> +
+    its ordered reduce), the full four-branch forward group as the model issues it (auto: one fp16x2 halo-patch launch
+    for the two high-resolution branches + the low-resolution branches' own launches), and the grouped BatchNorm
+    forward + backward of the four branches (HBM-bound; algorithmic bytes per element: statistics 4, apply 8, backward
+    reduce 8, backward apply 12 -- no residual, ReLU mask recomputed from y)."""
+    from hrseg_amd import _lib, ops
+    sizes, chans, xs, ws, fl = _branch_tensors(device, batch, size)
+    pr = _lib.CONV_PRECISION.get(conv_dtype, 0)
+    f16 = conv_dtype in ("auto", "fp16x2")
+    dys = [torch.randn(batch, h, h, c, device=device) * 1e-4 for c, h in zip(chans, sizes)]
     dws = [torch.zeros(c, 9, c, device=device) for c in chans]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-    def timed(fn, reps=20):
-        fn()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps * 1e-3
-
-    t_w = timed(lambda: ops.conv_wgrad_group(xs, dys, dws, 3, 1))
-    fl = sum(2.0 * batch * h * h * c * c * 9 for c, h in zip(chans, sizes))
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys] if f16 else None
+    t_w = _timed(lambda: ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms))
+    t_g = _timed(lambda: ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=pr))
     items = [dict(y=x, gamma=torch.ones(c, device=device), beta=torch.zeros(c, device=device),
                   rm=torch.zeros(c, device=device), rv=torch.ones(c, device=device),
                   nbt=torch.zeros((), dtype=torch.int64, device=device), momentum=0.1, eps=1e-5, residual=None, relu=True)
              for x, c in zip(xs, chans)]
     zc = ops.bn_fwd_group(items, True)
-    t_f = timed(lambda: ops.bn_fwd_group(items, True))
+    t_f = _timed(lambda: ops.bn_fwd_group(items, True))
     bw = [dict(dz=d.clone(), z=None, relu=True, y=x, coef=c_, dgamma=torch.zeros(c, device=device),
                dbeta=torch.zeros(c, device=device), dres=None, dres_accumulate=False)
           for d, x, (_, c_), c in zip(dys, xs, zc, chans)]
-    t_b = timed(lambda: ops.bn_bwd_group(bw, False))
+    t_b = _timed(lambda: ops.bn_bwd_group(bw, False))
     elems = sum(x.numel() for x in xs)
     gbs = elems * (12 + 20) / (t_f + t_b) / 1e9
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if f16 else FP32_MFMA_PEAK_TFLOPS
+    total = sum(fl)
     return [
-        {"bound": "mfma", "kernel": "wgrad_group_kernel<3,3,64,1> (weight gradient of the four 3x3 branch convs, B=%d)" % batch,
-         "achieved": round(fl / t_w / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-         "frac": round(fl / t_w / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(t_w * 1e6, 2)},
+        {"bound": "mfma", "kernel": ("wgrad9_sp_group_kernel3<fp16x2> + wgrad9_reduce_kernel" if f16 else "wgrad_group_kernel<3,3,64,1>") +
+         " (weight gradient of the four 3x3 branch convs, B=%d)" % batch,
+         "achieved": round(total / t_w / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(total / t_w / 1e12 / peak, 4), "avg_launch_us": round(t_w * 1e6, 2)},
+        {"bound": "mfma", "kernel": "four-branch forward group as issued (%s), B=%d" % (
+            "fp16x2 halo-patch launch + low-resolution launches" if f16 else "igemm_group_kernel", batch),
+         "achieved": round(total / t_g / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(total / t_g / 1e12 / peak, 4), "avg_us": round(t_g * 1e6, 2)},
         {"bound": "hbm", "kernel": "bn_{stats,finalize,apply}_group + bn_bwd_{reduce,finalize,apply}_group (four branches, B=%d)" % batch,
          "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
          "algorithmic_bytes_per_element": 32, "fwd_us": round(t_f * 1e6, 2), "bwd_us": round(t_b * 1e6, 2)},
     ]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE, doubled as the
-    gfx950 guide prescribes, + WRITE_SIZE; separate --pmc runs of one full train step, see profiles/README.md).
-    Counters cannot be collected from inside this process, so this is the recorded value, or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic_per_launch.csv")
+def pmc_value(kernel, what):
+    """Recorded rocprofv3 PMC results for `kernel` (counters cannot be collected from inside this process):
+    'traffic'   -- HBM bytes per launch: FETCH_SIZE (doubled, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
+                   separate --pmc passes over full train steps (profiles/README.md)
+    'mfma_busy' -- SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES ... ) as recorded in the csv's mfma_busy column
+    -> (value, source) or (None, None)."""
+    import csv
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    fname = {"traffic": "r02_pmc_traffic_per_launch.csv", "mfma_busy": "r02_pmc_mfma_busy.csv"}[what]
     try:
-        import csv
-        for row in csv.DictReader(open(path)):
-            if row["kernel"] == kernel:
-                mb = float(row["FETCH_bytes_MB_corrected_x2"]) + float(row["WRITE_MB"])
-                return round(mb * 2**20), "profiles/r01e_pmc_traffic_per_launch.csv (rocprofv3 --pmc, all fwd+dgrad launches of a step)"
+        for row in csv.DictReader(open(os.path.join(root, fname))):
+            if row["kernel"].startswith(kernel):
+                if what == "traffic":
+                    mb = float(row["FETCH_bytes_MB_corrected_x2"]) + float(row["WRITE_MB"])
+                    return round(mb * 2**20), "profiles/%s (rocprofv3 --pmc, all launches of full train steps)" % fname
+                return round(float(row["mfma_busy"]), 4), "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES-based, see README)" % fname
     except (OSError, KeyError, ValueError):
         pass
     return None, None
