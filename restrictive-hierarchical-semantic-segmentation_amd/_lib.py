@@ -112,6 +112,7 @@ RAW_PROTOTYPES = {
     "hrseg_comm_allreduce_async": [_p, _p, _l, _p],
     "hrseg_comm_wait": [_p, _p],
     "hrseg_comm_destroy": [_p],
+    "hrseg_set_scratch": [_p, C.c_size_t],
 }
 
 _lib.hrseg_last_error_string.restype = C.c_char_p
@@ -126,6 +127,24 @@ _lib.hrseg_conv_wgrad_workspace_bytes.argtypes = [_i, C.POINTER(ConvShape)]
 def conv_wgrad_workspace_bytes(shapes, n=None):
     """bytes of workspace the nine-tap weight-gradient path wants for these problems (0: not applicable)"""
     return int(_lib.hrseg_conv_wgrad_workspace_bytes(len(shapes) if n is None else n, shapes))
+
+
+_scratch = None
+
+
+def ensure_scratch(device):
+    """hand the library its convolution scratch buffer (hrseg_set_scratch) the first time a convolution runs;
+    HRSEG_SCRATCH_MB=0 leaves it detached (the layers that want it take their other kernels)"""
+    global _scratch
+    if _scratch is not None:
+        return
+    import torch
+    nbytes = int(os.environ.get("HRSEG_SCRATCH_MB", "64")) << 20
+    if nbytes == 0:
+        _scratch = False
+        return
+    _scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    call_raw("hrseg_set_scratch", _scratch.data_ptr(), nbytes)
 
 
 _lib.hrseg_tune.restype = _i
@@ -159,7 +178,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 5     # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 6     # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

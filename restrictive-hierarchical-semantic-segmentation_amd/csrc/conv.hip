@@ -22,6 +22,7 @@
 //  * Cin <= 4 (the image layer): direct VALU kernels.
 #include "common.h"
 #include <string.h>
+#include <stdint.h>
 
 // ---------------------------------------------------------------------------
 struct IgemmArgs {
@@ -44,6 +45,7 @@ struct IgemmArgs {
   const float* xmax;         // fp16x2: device scalar max|x| of the pixel operand when it is a gradient (else null)
   float wscale, wscale_inv;  // fp16x2: fixed power-of-two scale of the weight operand and its inverse (1 otherwise)
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
+  const unsigned char* wimg; // wave-specialised patch body: pre-split weight image (sp_weight_image_kernel), else null
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for
@@ -395,6 +397,7 @@ static int finalize_args(IgemmArgs& a) {
   a.rcp_hw = big ? 0.f : 1.0f / (float)(a.Ho * a.Wo);
   a.rcp_w = big ? 0.f : 1.0f / (float)a.Wo;
   a.direct_out = (a.Hy == a.Ho && a.Wy == a.Wo && a.oys == 1 && a.oxs == 1 && a.oy0 == 0 && a.ox0 == 0) ? 1 : 0;
+  a.wimg = nullptr;
   a.oy_min = a.ox_min = 0;
   for (int t = 0; t < a.ntaps; ++t) {
     const int oy = (int)((a.offy_pk >> (4 * t)) & 15) - 8, ox = (int)((a.offx_pk >> (4 * t)) & 15) - 8;
@@ -477,8 +480,8 @@ static int launch_patch_sp(const IgemmArgs& a, int wtn, int cs, hipStream_t st) 
     const int per = ceil_div(ntotal, 256 * g_sp_persist);
     blocks = ceil_div(ntotal, per);
   }
-  const dim3 grid((unsigned)blocks);
   const int flip = patch_flip(a);
+  const dim3 grid((unsigned)blocks);
 #define PS(N_, C_) if (wtn == N_ && cs == C_) { \
     if (flip) hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 1>), grid, dim3(256), 0, st, a, ntotal); \
     else hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 0>), grid, dim3(256), 0, st, a, ntotal); \
@@ -486,6 +489,149 @@ static int launch_patch_sp(const IgemmArgs& a, int wtn, int cs, hipStream_t st) 
   PS(3, 3) PS(3, 4) PS(4, 3) PS(4, 4) PS(6, 3) PS(6, 4)
 #undef PS
   return 1;
+}
+
+// ---- wave-specialised halo-patch path (fp16x2; conv_sp.h: igemm_patch_ws_body)
+// The pre-split weight images live in a scratch buffer the host hands over once (hrseg_set_scratch; device memory is
+// the caller's, as everywhere in this ABI).  It is cut into four regions, one per stream that launches convolutions,
+// each a ring: an image is written and read by kernels of ONE stream, in order, so reusing a slot after the ring
+// wraps needs no synchronisation.  Without a scratch buffer the path is simply not taken.
+static int g_sp_ws = 1;                 // hrseg_tune "sp_ws": 0 = never use the wave-specialised body
+static int g_ws_n48 = 0;                // hrseg_tune "sp_ws_n48": 0 = 48-channel tilings stay on the block-synchronous kernels
+static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile padding accepted, percent of the image
+static unsigned char* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+struct ScratchRegion { hipStream_t st; bool used; size_t head; };
+static ScratchRegion g_regions[4];
+extern "C" int hrseg_set_scratch(void* ptr, size_t bytes) {
+  HRSEG_CHECK_ARG((ptr && bytes >= (1u << 20)) || (!ptr && bytes == 0), "hrseg_set_scratch: need a buffer of at least 1 MiB, or (null, 0)");
+  HRSEG_CHECK_ARG(((uintptr_t)ptr & 255) == 0, "hrseg_set_scratch: the buffer must be 256-byte aligned");
+  g_scratch = (unsigned char*)ptr;
+  g_scratch_bytes = bytes;
+  for (auto& r : g_regions) r = ScratchRegion{nullptr, false, 0};
+  return 0;
+}
+static unsigned char* scratch_alloc(hipStream_t st, size_t bytes) {
+  if (!g_scratch) return nullptr;
+  const size_t region = (g_scratch_bytes / 4) & ~(size_t)255;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > region) return nullptr;
+  int r = -1;
+  for (int i = 0; i < 4 && r < 0; ++i)
+    if (g_regions[i].used && g_regions[i].st == st) r = i;
+  for (int i = 0; i < 4 && r < 0; ++i)
+    if (!g_regions[i].used) { g_regions[i] = ScratchRegion{st, true, 0}; r = i; }
+  if (r < 0) return nullptr;
+  if (g_regions[r].head + bytes > region) g_regions[r].head = 0;
+  unsigned char* p = g_scratch + (size_t)r * region + g_regions[r].head;
+  g_regions[r].head += bytes;
+  return p;
+}
+// tiling of the wave-specialised body for a problem: 0 = not eligible, 1 = 48 channels x 48-channel K stages on
+// 8 x 16 pixel tiles, 2 = 96 x 48, 3 = 64 x 64, 4 = 48 x 48 on 16 x 16 pixel tiles (a 48-channel slab on 8 rows is
+// 18 MFMAs per wave: too short for the producers to keep up)
+static const int WS_WTN[5] = {0, 3, 6, 4, 3}, WS_CS[5] = {0, 3, 3, 4, 3}, WS_TH[5] = {0, 8, 8, 8, 16};
+static long ws_tiles(const IgemmArgs& a, int kind) {
+  return (long)a.B * ceil_div(a.Ho, WS_TH[kind]) * ceil_div(a.Wo, 16) * (a.N / (16 * WS_WTN[kind]));
+}
+static double ws_waste(const IgemmArgs& a, int kind) {
+  return (double)(ceil_div(a.Ho, WS_TH[kind]) * WS_TH[kind]) * (ceil_div(a.Wo, 16) * 16) / ((double)a.Ho * a.Wo);
+}
+static int ws_kind(const IgemmArgs& a) {
+  if (!g_sp_ws || !g_scratch || patch_flip(a) < 0 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
+    return 0;
+  if (a.oy_min != -1 || a.ox_min != -1) return 0;
+  int kind = (a.K % 48 == 0 && a.N % 48 == 0) ? 1 : (a.K % 64 == 0 && a.N % 64 == 0) ? 3 : 0;
+  if (!kind) return 0;
+  if (kind == 1) {
+    if (a.N % 96 == 0 && ws_tiles(a, 2) >= 160) kind = 2;
+    else if (ws_waste(a, 4) <= 1.10 && ws_tiles(a, 4) >= 256) kind = 4;
+  }
+  if (ws_waste(a, kind) * 100 > g_ws_waste) return 0;
+  if ((kind == 1 || kind == 4) && !g_ws_n48) return 0;
+  return kind;
+}
+static size_t ws_image_bytes(const IgemmArgs& a, int kind) {
+  const int wtn = WS_WTN[kind], cs = WS_CS[kind];
+  return (size_t)(a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2) * (size_t)(2 * 16 * wtn * 64);
+}
+// writes the weight image of problem `a` (sets a.wimg); false: no scratch space
+static bool ws_make_image(IgemmArgs& a, int kind, hipStream_t st) {
+  unsigned char* img = scratch_alloc(st, ws_image_bytes(a, kind));
+  if (!img) return false;
+  const int wtn = WS_WTN[kind], cs = WS_CS[kind];
+  const dim3 grid((unsigned)((a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2)));
+  if (kind == 1 || kind == 4) hipLaunchKernelGGL((sp_weight_image_kernel<3, 3>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
+  else if (kind == 2) hipLaunchKernelGGL((sp_weight_image_kernel<6, 3>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
+  else hipLaunchKernelGGL((sp_weight_image_kernel<4, 4>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
+  a.wimg = img;
+  return true;
+}
+static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
+  const int ntotal = (int)ws_tiles(a, kind);
+  if (!ws_make_image(a, kind, st)) return 1;
+  const int per = ceil_div(ntotal, 256);
+  const dim3 grid((unsigned)ceil_div(ntotal, per));
+  const int flip = patch_flip(a);
+#define WS1(K_, H_, N_, C_) if (kind == K_) { \
+    if (flip) hipLaunchKernelGGL((igemm_patch_ws_kernel<4, H_, N_, C_, 1>), grid, dim3(512), 0, st, a, ntotal); \
+    else hipLaunchKernelGGL((igemm_patch_ws_kernel<4, H_, N_, C_, 0>), grid, dim3(512), 0, st, a, ntotal); \
+    return 0; }
+  WS1(1, 8, 3, 3) WS1(2, 8, 6, 3) WS1(3, 8, 4, 4) WS1(4, 16, 3, 3)
+#undef WS1
+  return 1;
+}
+// One launch for several problems: the 256 persistent blocks are divided among the problems in proportion to their
+// slab counts, then blocks move from the problem that finishes first to the one that finishes last while that helps.
+static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st) {
+  IgemmGroup g;
+  g.n = n;
+  long cost[MAXG], ntot[MAXG], total = 0;
+  int blocks[MAXG], flip = -1;
+  for (int i = 0; i < n; ++i) {
+    const int f = patch_flip(a[i]);
+    if (flip >= 0 && f != flip) return 1;
+    flip = f;
+    const int cs = WS_CS[kinds[i]];
+    ntot[i] = ws_tiles(a[i], kinds[i]);
+    cost[i] = (long)(a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
+    total += ntot[i] * cost[i];
+  }
+  int used = 0;
+  for (int i = 0; i < n; ++i) {
+    blocks[i] = (int)(256 * ntot[i] * cost[i] / total);
+    if (blocks[i] < 1) blocks[i] = 1;
+    if (blocks[i] > ntot[i]) blocks[i] = (int)ntot[i];
+    used += blocks[i];
+  }
+  auto span = [&](int i, int b) { return (long)ceil_div((int)ntot[i], b) * cost[i]; };
+  for (int it = 0; it < 512; ++it) {
+    int hi = 0, lo = -1;
+    for (int i = 1; i < n; ++i)
+      if (span(i, blocks[i]) > span(hi, blocks[hi])) hi = i;
+    if (blocks[hi] >= ntot[hi]) break;
+    if (used < 256) { ++blocks[hi]; ++used; continue; }
+    for (int i = 0; i < n; ++i)          // the donor: the problem that stays shortest with one block less
+      if (i != hi && blocks[i] > 1 && (lo < 0 || span(i, blocks[i] - 1) < span(lo, blocks[lo] - 1))) lo = i;
+    if (lo < 0 || span(lo, blocks[lo] - 1) >= span(hi, blocks[hi])) break;
+    --blocks[lo];
+    ++blocks[hi];
+  }
+  for (int i = 0; i < n; ++i)
+    if (!ws_make_image(a[i], kinds[i], st)) return 1;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    const int per = ceil_div((int)ntot[i], blocks[i]);
+    g.tiles[i] = ceil_div((int)ntot[i], per);      // blocks that have work
+    g.ksplit[i] = (int)ntot[i];
+    end += g.tiles[i];
+    g.blk_end[i] = end;
+    g.kind[i] = kinds[i];
+    g.a[i] = a[i];
+  }
+  if (flip) hipLaunchKernelGGL((igemm_patch_ws_group_kernel<1>), dim3(end), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((igemm_patch_ws_group_kernel<0>), dim3(end), dim3(512), 0, st, g);
+  return 0;
 }
 
 template <int NS>
@@ -522,7 +668,9 @@ static void set_sp_scales(IgemmArgs& a, int precision, const float* grad_absmax)
 // the small ones; weight gradients: fp16x2 throughout
 static int resolve_auto(const IgemmArgs& a, int precision) {
   if (precision != HRSEG_CONV_AUTO) return precision;
-  return a.M >= 8192 ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
+  if (a.M >= 8192) return HRSEG_CONV_FP16X2;
+  const int k = ws_kind(a);           // the wave-specialised patch body also wins on small images
+  return (k && ws_tiles(a, k) >= 96) ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
 }
 
 static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
@@ -531,6 +679,10 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
   precision = resolve_auto(a, precision);
   if (const int ns = sp_pieces(precision)) {
     const SpPlan pl = plan_sp(a);
+    if (ns == 4 && !g_sp_wtn) {
+      const int kind = ws_kind(a);
+      if (kind && ws_tiles(a, kind) >= 96 && launch_ws_single(a, kind, st) == 0) return 0;
+    }
     if (const int cs = patch_cs(a, pl.wtn)) {
       const int rc = ns == 4 ? launch_patch_sp<4>(a, pl.wtn, cs, st) : ns == 3 ? launch_patch_sp<3>(a, pl.wtn, cs, st) : ns == 2 ? launch_patch_sp<2>(a, pl.wtn, cs, st) : launch_patch_sp<1>(a, pl.wtn, cs, st);
       if (rc == 0) return 0;
@@ -595,7 +747,34 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
 // HRSEG_CONV_AUTO on a group: the problems the halo-patch body takes go out as one fp16x2 launch (a
 // low-resolution branch inside a patch launch would run at the patch body's occupancy); of the rest, the small ones
 // (< 8192 pixels) as one fp32 launch and the others one by one
-static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st) {
+static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, bool try_ws = true) {
+  if (try_ws && g_sp_ws && g_scratch && !g_sp_wtn) {
+    // the problems the wave-specialised body takes go out as one launch of 256 persistent blocks; the rest as before
+    IgemmArgs wsa[MAXG], rest[MAXG];
+    int kinds[MAXG], nw = 0, nr = 0;
+    for (int i = 0; i < n; ++i) {
+      IgemmArgs f = a[i];
+      if (finalize_args(f)) return 1;
+      const int k = ws_kind(f);
+      if (k && ws_tiles(f, k) >= 96) { wsa[nw] = f; kinds[nw++] = k; }
+      else rest[nr++] = a[i];
+    }
+    // (a lone taker next to a 48-channel high-resolution branch: the two share one halo-patch group launch instead,
+    // measured 79 us against 41 + 49)
+    bool pair = false;
+    if (nw == 1 && nr == 1) {
+      IgemmArgs f = rest[0];
+      pair = finalize_args(f) == 0 && f.N % 48 == 0 && patch_cs(f, 3) == 3;
+    }
+    if (nw >= 1 && !pair && launch_ws_group(wsa, kinds, nw, st) == 0) {
+      if (nr == 0) return 0;
+      if (nr == 1) { const int e = dispatch_igemm(rest[0], HRSEG_CONV_AUTO, st); return e < 0 ? e : (e ? 1 : 0); }
+      if (dispatch_igemm_group_auto(rest, nr, st, false) == 0) return 0;
+      for (int i = 0; i < nr; ++i)
+        if (int e = dispatch_igemm(rest[i], HRSEG_CONV_AUTO, st)) return e < 0 ? e : 1;
+      return 0;
+    }
+  }
   IgemmArgs hi[MAXG], lo[MAXG];
   int nh = 0, nl = 0;
   for (int i = 0; i < n; ++i) {
@@ -1565,7 +1744,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)

@@ -152,6 +152,7 @@ struct SpLds {
   static constexpr int BYTES = 2 * STAGE;        // double buffered
 };
 
+#define SP_DEPTH 3        // slabs of global-load look-ahead in igemm_sp_body
 // One output tile of one convolution.  `ks_idx / ks_n`: split-K slice of the slab list (partial sums are
 // added with fp32 atomics, as in igemm_body).
 template <int NS, int WTM, int WTN>
@@ -226,16 +227,23 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
     wst[i] = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
   }
 
-  // running unit counters (scalar): tap and chunk of the next slab's two units
+  // running unit counters (scalar): tap and chunk of the next slab's two units.  Loads run SP_DEPTH slabs
+  // ahead of their use in a ring of register sets: a slab of this body is 6-36 MFMAs per wave (0.1-0.3 us), an
+  // L2 round trip under load is several times that, and with one or two blocks per CU nothing else hides it
+  // (measured: 1.2 us per slab with one slab of look-ahead on the low-resolution branches).  Every load is
+  // issued unconditionally -- past the end of the slice with out-of-range offsets (zero fill, no traffic) -- so
+  // the vmcnt bookkeeping stays exact and a slab waits for its own loads only.
+  constexpr int D = SP_DEPTH;
   int u_next = 2 * s_lo;
-  f32x4 ra[WTM][2], rwt[W_LOADS];
-  auto issue_loads = [&]() {
+  const int u_end = min(nunits, 2 * s_hi);
+  f32x4 ra[D][WTM][2], rwt[D][W_LOADS];
+  auto issue_loads = [&](f32x4 (&ra)[WTM][2], f32x4 (&rwt)[W_LOADS]) {
     unsigned soff[2], wsoff[2];
     int tapbit[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int u = u_next + h;
-      const bool live = u < nunits;
+      const bool live = u < u_end;
       const int t = live ? u / kch : 0;
       const int c = u - t * kch;
       const int dy = (int)((p.offy_pk >> (4 * t)) & 15) - 8 - p.oy_min, dx = (int)((p.offx_pk >> (4 * t)) & 15) - 8 - p.ox_min;
@@ -244,13 +252,13 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
       tapbit[h] = live ? t : 31;          // bit 31 of inval is set only for rows past M; dead unit: forced below
       if (!live) soff[h] = 0;
     }
-    const bool live1 = u_next + 1 < nunits;
+    const bool live0 = u_next < u_end, live1 = u_next + 1 < u_end;
 #pragma unroll
     for (int m = 0; m < WTM; ++m) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         // -1 (out of range: zero fill) when the tap is outside the image for this row or the unit is dead
-        const int oob = __builtin_amdgcn_sbfe(inval[m], tapbit[h], 1) | ((h == 1 && !live1) ? -1 : 0);
+        const int oob = __builtin_amdgcn_sbfe(inval[m], tapbit[h], 1) | ((h == 1 ? !live1 : !live0) ? -1 : 0);
         ra[m][h] = buf_load4(rx, voff[m] | (unsigned)oob, (int)soff[h]);
       }
     }
@@ -264,7 +272,7 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
   };
 
   bf16x8 xf[WTM][sp_np(NS)];
-  auto split_store = [&](int buf) {
+  auto split_store = [&](int buf, const f32x4 (&ra)[WTM][2], const f32x4 (&rwt)[W_LOADS]) {
     unsigned char* base = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
@@ -287,25 +295,28 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
 
   const int foff = r16 * 64 + lds_slot(r16, g) * 16;       // weight fragment of this lane inside a 16-row tile
 
-  if (nslabs > 0) {
-    issue_loads();
-    split_store(0);
-  }
+  // slab s lives in register set s % D; the slab count is padded to a multiple of D (dead slabs are zeros)
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_loads(ra[d], rwt[d]);
+  split_store(0, ra[0], rwt[0]);
   __syncthreads();
-  for (int s = 0; s < nslabs; ++s) {
-    const bool more = s + 1 < nslabs;
-    if (more) issue_loads();
-    const unsigned char* base = lds + (s & 1) * STAGE;
+  for (int s0 = 0; s0 < nslabs; s0 += D) {
 #pragma unroll
-    for (int n = 0; n < WTN; ++n) {
-      bf16x8 wf[sp_np(NS)];
+    for (int d = 0; d < D; ++d) {
+      const int s = s0 + d;
+      issue_loads(ra[d], rwt[d]);                        // slab s + D; set d held slab s, consumed a slab ago
+      const unsigned char* base = lds + (s & 1) * STAGE;
 #pragma unroll
-      for (int q = 0; q < sp_np(NS); ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
+      for (int n = 0; n < WTN; ++n) {
+        bf16x8 wf[sp_np(NS)];
 #pragma unroll
-      for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma<NS>(wf, xf[m], acc[n][m]);
+        for (int q = 0; q < sp_np(NS); ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
+#pragma unroll
+        for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma<NS>(wf, xf[m], acc[n][m]);
+      }
+      split_store((s + 1) & 1, ra[(d + 1) % D], rwt[(d + 1) % D]);      // slab s + 1
+      __syncthreads();
     }
-    if (more) split_store((s + 1) & 1);
-    __syncthreads();
   }
 
   // epilogue: lane holds channels n0+16n+4g..+3 of pixel row r16 of every tile
@@ -793,6 +804,393 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int chunk = (ntotal + gridDim.x - 1) / gridDim.x;
   const int first = blockIdx.x * chunk;
   igemm_patch_sp_body<NS, TH, WTN, CS, FLIP>(p, lds, first, 1, min(first + chunk, ntotal));
+}
+
+// --------------------------------------------------------------------------- halo patch, wave-specialised (8 waves)
+// In igemm_patch_sp_body every wave does everything: its MFMA burst is followed by the split + store of the next
+// weight slab, the fragment reads and the barrier, and two waves per SIMD from two blocks do not hide that (MFMA-busy
+// 0.30-0.34).  Here a 512-thread block splits the roles.  Waves 0-3 (one per SIMD) are CONSUMERS: per slab they issue
+// the MFMAs of the current slab in an order that never puts two dependent products back to back, with the LDS reads
+// of the NEXT slab's fragments pinned between them (sched_barrier keeps the compiler from sinking the reads to their
+// uses), and nothing else.  Waves 4-7 are PRODUCERS: a wave issues one instruction every four cycles at best, so the
+// producer has ~140 issue slots per 36-MFMA slab; splitting the weight slab on the fly (18 VALU per 16-byte granule,
+// three granules per thread) does not fit, splitting it once does: the weights come PRE-SPLIT from a global image
+// laid out slab by slab exactly like the LDS buffer (sp_weight_image_kernel, one small launch per convolution) and
+// the producers only copy them -- global -> registers four slabs ahead -> ds_write_b128 two slabs ahead -- and stage
+// the next K stage's patch into the second patch buffer, one granule per slab.  One barrier per slab orders both
+// roles.  One block per CU, persistent over a range of tiles.
+template <int NS, int TH, int WTN, int CS>
+struct SpPatchWsLds {
+  using P = SpPatchLds<NS, TH, WTN, CS>;
+  static constexpr int BYTES = 2 * P::PATCH + 3 * P::WSTAGE;       // two patch buffers, three weight slabs
+  static constexpr int NSLAB = (9 * CS + 1) / 2;
+};
+
+// weight image: for every (channel tile, K stage, slab) the WSTAGE bytes the LDS weight buffer holds for it
+template <int WTN, int CS>
+__global__ __launch_bounds__(256) void sp_weight_image_kernel(const float* __restrict__ w, unsigned char* __restrict__ img,
+                                                              int K, float wscale) {
+  using L = SpPatchLds<4, 8, WTN, CS>;
+  constexpr int BN = 16 * WTN, WG = BN * 8, NU = 9 * CS, NSLAB = (NU + 1) / 2;
+  const int nks = K / (16 * CS);
+  const int slab = blockIdx.x % NSLAB;
+  const int ks = (blockIdx.x / NSLAB) % nks;
+  const int nt = blockIdx.x / (NSLAB * nks);
+  unsigned char* dst = img + (size_t)blockIdx.x * L::WSTAGE;
+  for (int f = threadIdx.x; f < WG; f += 256) {
+    const int n = f >> 3, unit = (f >> 2) & 1, gq = f & 3;
+    const int u = 2 * slab + unit;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (u < NU) {
+      const int t = u / CS, c = u - t * CS;
+      v = *reinterpret_cast<const f32x4*>(w + ((size_t)(nt * BN + n) * 9 + t) * K + ks * CS * 16 + c * 16 + 4 * gq);
+    }
+    u32x2 pc[2];
+    sp_split4<4>(v, pc, wscale);
+    const int o = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
+    *reinterpret_cast<u32x2*>(dst + o) = pc[0];
+    *reinterpret_cast<u32x2*>(dst + L::WPIECE + o) = pc[1];
+  }
+}
+
+template <int NS, int TH, int WTN, int CS, int FLIP>
+__device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end) {
+  static_assert(NS == 4, "the wave-specialised body is the fp16x2 one");
+  using L = SpPatchLds<NS, TH, WTN, CS>;
+  constexpr int RPW = TH / 4, BN = 16 * WTN, PW = 18, PP = L::PP;
+  // patch granules (16 bytes of fp32 = 4 channels): a round of the 256 producer threads covers PR whole pixels,
+  // thread -> (pixel ptid / GPP within the round, granule ptid % GPP of the pixel), so that a granule's pixel is
+  // pix0 + PR * i with no division in the loop (CS = 3: 252 threads work, 4 idle)
+  constexpr int GPP = CS * 4, PR = 256 / GPP;
+  constexpr int P_LOADS = (PP + PR - 1) / PR;              // rounds per K stage
+  constexpr int W16 = L::WSTAGE / 16, W_LOADS = (W16 + 255) / 256;     // 16-byte granules of a pre-split weight slab
+  constexpr int NU = 9 * CS, NSLAB = (NU + 1) / 2;
+  constexpr int D = 4;                                     // producer look-ahead, slabs
+  static_assert(NSLAB % 2 == 0, "register-set parity must restart with every K stage");
+  constexpr int GPS = (P_LOADS + NSLAB - 2 - D) / (NSLAB - 1 - D);     // patch granules per thread and slab
+  constexpr int P_SLABS = (P_LOADS + GPS - 1) / GPS;                   // slabs of a stage that stage patch granules
+  static_assert(P_SLABS + D <= NSLAB - 1, "the next K stage's patch is complete one slab before the stage ends");
+  unsigned char* lpatch = lds;                             // [2][PATCH]
+  unsigned char* lw = lds + 2 * L::PATCH;                  // [3][WSTAGE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool consumer = __builtin_amdgcn_readfirstlane(wave) < 4;      // wave-uniform: a scalar branch
+  const int ptid = tid & 255;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int H = p.Ho, W = p.Wo;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
+  const int ntn = p.N / BN;
+  const int nks = p.K / (16 * CS);
+  if (first >= end) return;
+  const int total = (end - first) * nks * NSLAB;           // slabs of this block
+
+  // tile t -> (channel tile fastest, then tile column, tile row, image); walked incrementally (the divisions
+  // happen once per block: a producer wave has no issue slots to spare for them)
+  struct Geom { int b, y0, x0, nt; };
+  auto tile_geom = [&](int t) {
+    Geom q;
+    q.nt = t % ntn;
+    int mt = t / ntn;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    q.b = mt / tiles_y;
+    q.y0 = ty * TH; q.x0 = tx * 16;
+    return q;
+  };
+  auto tile_next = [&](Geom& q) {
+    if (++q.nt < ntn) return;
+    q.nt = 0;
+    q.x0 += 16;
+    if (q.x0 < tiles_x * 16) return;
+    q.x0 = 0;
+    q.y0 += TH;
+    if (q.y0 < tiles_y * TH) return;
+    q.y0 = 0;
+    ++q.b;
+  };
+
+  if (consumer) {
+    float xscale, xinv;
+    sp_pow2_scale(p.xmax, xscale, xinv);
+    const float oscale = xinv * p.wscale_inv;
+    const int foff = r16 * 64 + lds_slot(r16, g) * 16;
+    const int prow0 = (wave * RPW) * PW + r16;
+    const int pbase = prow0 * 32;
+    constexpr int NP = sp_np(NS);
+    constexpr int UNITS = RPW * NP + WTN * NP;             // fragment registers (8 halfs each) of a slab
+    constexpr int MM = WTN * RPW * 3;                      // MFMAs of a slab
+    // fragment r of slab `slab` (compile-time) -> register set
+    auto read_unit = [&](int slab, int wboff, int pbuf, int r, bf16x8 (&xf)[RPW][NP], bf16x8 (&wf)[WTN][NP]) {
+      if (r < RPW * NP) {
+        const int m = r / NP, q = r % NP;
+        const int uA = 2 * slab, uB = 2 * slab + 1;
+        const int tA = uA / CS, cA = uA - tA * CS;
+        const int tB = (uB < NU) ? uB / CS : 0, cB = (uB < NU) ? uB - tB * CS : 0;
+        const int dA = (FLIP ? 2 - tA / 3 : tA / 3) * PW + (FLIP ? 2 - tA % 3 : tA % 3);
+        const int dB = (FLIP ? 2 - tB / 3 : tB / 3) * PW + (FLIP ? 2 - tB % 3 : tB % 3);
+        const unsigned char* pb = lpatch + pbuf * L::PATCH + q * L::PPIECE;
+        const int pa = prow0 + m * PW + dA, pbx = prow0 + m * PW + dB;
+        const int oa = cA * L::CHUNK + pbase + (m * PW + dA) * 32 + ((g ^ (2 * ((pa >> 3) & 1))) << 3);
+        const int ob = cB * L::CHUNK + pbase + (m * PW + dB) * 32 + ((g ^ (2 * ((pbx >> 3) & 1))) << 3);
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(pb + oa);
+        u32x2 hi = u32x2{0u, 0u};
+        if (uB < NU) hi = *reinterpret_cast<const u32x2*>(pb + ob);
+        xf[m][q] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+      } else {
+        const int i = r - RPW * NP, n = i / NP, q = i % NP;
+        wf[n][q] = *reinterpret_cast<const bf16x8*>(lw + wboff + q * L::WPIECE + n * 1024 + foff);
+      }
+    };
+    f32x4 acc[WTN][RPW];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int n = 0; n < WTN; ++n)
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](const Geom& q) {
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) {
+        const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+        if (oy >= H || ox >= W) continue;
+        float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
+#pragma unroll
+        for (int n = 0; n < WTN; ++n) {
+          const int ch = q.nt * BN + 16 * n + 4 * g;
+          f32x4 v = acc[n][m] * oscale;
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+          *reinterpret_cast<f32x4*>(yrow + ch) = v;
+        }
+      }
+    };
+    bf16x8 xfr[2][RPW][NP], wfr[2][WTN][NP];
+    Geom cur = tile_geom(first);
+    __syncthreads();                       // the producers' prologue: first patch, weight slabs 0 and 1
+#pragma unroll
+    for (int r = 0; r < UNITS; ++r) read_unit(0, 0, 0, r, xfr[0], wfr[0]);
+    zero_acc();
+    int wb = 0, pb = 0;                    // weight buffer offset of the CURRENT slab, patch buffer of the CURRENT stage
+    for (int t = first;; ++t) {
+      bool have_next = false;
+      for (int ks = 0; ks < nks; ++ks) {
+        const bool last_ks = ks + 1 == nks;
+        have_next = (last_ks ? t + 1 : t) < end;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+          const int wb1 = (wb == 2 * L::WSTAGE) ? 0 : wb + L::WSTAGE;
+          // the next slab's fragments: slab s+1 of this patch, or slab 0 of the next stage's patch (complete since
+          // the barrier before this slab; past the block's last stage the reads fetch stale data nobody uses)
+          const int nslab = (s + 1 < NSLAB) ? s + 1 : 0;
+          const int npb = (s + 1 < NSLAB) ? pb : pb ^ 1;
+          int k = 0;
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) {
+#pragma unroll
+              for (int m = 0; m < RPW; ++m) {
+                // products in the order of sp_mma (w1 x0, w0 x1, w0 x0) per accumulator, WTN*RPW MFMAs apart
+                const f16x8 wv = __builtin_bit_cast(f16x8, wfr[s & 1][n][pr == 0 ? 1 : 0]);
+                const f16x8 xv = __builtin_bit_cast(f16x8, xfr[s & 1][m][pr == 1 ? 1 : 0]);
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int r = k * UNITS / MM; r < (k + 1) * UNITS / MM; ++r)
+                  read_unit(nslab, wb1, npb, r, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                ++k;
+              }
+            }
+          }
+          if (s == NSLAB - 1 && last_ks) { store_tile(cur); zero_acc(); }
+          __syncthreads();
+          wb = wb1;
+        }
+        pb ^= 1;
+        if (last_ks) tile_next(cur);
+      }
+      if (!have_next) break;
+    }
+    for (int k = total; k & (D - 1); ++k) __syncthreads();      // the producers' loop is unrolled by D slabs
+  } else {
+    // Producers run a flat loop over the block's slabs (j = 0 .. total-1, indices runtime and wave-uniform): at slab j
+    // they store weight slab j+2 (loaded four slabs earlier into register set (j+2)%4) and issue the loads of slab
+    // j+6 into the same set; the next K stage's patch goes granule by granule, loaded at in-stage slab s and stored
+    // at s+4.  The loads and their waits are written by hand: with conditional stores in the loop the compiler's
+    // waitcnt pass falls back to vmcnt(0) before every use, i.e. one slab of look-ahead (measured: the producers then
+    // take 2.5x the consumers' time).  Every slab issues exactly W_LOADS weight loads and then GPS patch loads, valid
+    // or not (out-of-range offsets cost no traffic), so the number of younger loads behind any load is a constant
+    // and `s_waitcnt vmcnt(constant)` waits for exactly the loads a store needs.
+    float xscale, xinv;
+    sp_pow2_scale(p.xmax, xscale, xinv);
+    const int per_tile = nks * NSLAB;                      // slabs (= weight image entries) per tile
+    auto rsrc_words = [](const void* base, size_t bytes) {
+      const unsigned long long a = (unsigned long long)base;
+      i32x4_t r;
+      r[0] = (int)(unsigned)(a & 0xffffffffull);
+      r[1] = (int)(unsigned)((a >> 32) & 0xffffull);
+      r[2] = (int)(unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes);
+      r[3] = HRSEG_BUF_FLAGS;
+      return r;
+    };
+    auto ld16 = [](f32x4& dst, const i32x4_t& rs, unsigned voff, int soff) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    const i32x4_t rw = rsrc_words(p.wimg, (size_t)ntn * per_tile * L::WSTAGE);
+    constexpr int PER_SLAB = W_LOADS + GPS;                // loads issued per slab, in this order: weights, patch
+    constexpr int WAIT_W = GPS + (D - 1) * PER_SLAB;       // loads younger than a weight set at the slab that stores it
+    constexpr int WAIT_P = (D - 1) * PER_SLAB + W_LOADS;   // ... than the last patch granule of a slab, ditto
+    static_assert(WAIT_W < 64 && WAIT_P < 64, "vmcnt is a 6-bit counter");
+    const int pix0 = ptid / GPP, prem = ptid - pix0 * GPP;
+    const bool pwork = pix0 < PR;                          // (CS = 3: the last four threads stage no patch granule)
+    const unsigned prem16 = (unsigned)prem * 16u;
+    const int pst0 = (prem >> 2) * L::CHUNK, pq = prem & 3;
+    const unsigned ldx4 = (unsigned)p.ldx * 4u;
+    // descriptor of the image the patch comes from (rebuilt when the stage cursor moves to another image)
+    auto image_rsrc = [&](int b) { return rsrc_words(p.x + (size_t)b * H * W * p.ldx, (size_t)H * W * p.ldx * 4); };
+    auto patch_load1 = [&](f32x4& dst, const i32x4_t& rx, const Geom& q, int ks, int i, bool valid) {
+      const int pix = pix0 + PR * i;
+      const int py = (pix * 3641) >> 16, px = pix - py * PW;           // pix / 18 for pix < 2^12
+      const int iy = q.y0 - 1 + py, ix = q.x0 - 1 + px;
+      const bool ok = valid & pwork & (pix < PP) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(iy * W + ix) * ldx4 + prem16 : HRSEG_BUF_OOB;
+      ld16(dst, rx, off, ks * CS * 64);
+    };
+    auto patch_store1 = [&](const f32x4& v, int i, int pbuf) {
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(v, pc, xscale);
+      const int pix = pix0 + PR * i;
+      const int o = pbuf * L::PATCH + pst0 + pix * 32 + ((pq ^ (2 * ((pix >> 3) & 1))) << 3);
+      if (pwork & (pix < PP)) {
+#pragma unroll
+        for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
+      }
+    };
+    f32x4 rw4[D][W_LOADS], rpg[D][GPS];
+    Geom cur = tile_geom(first);
+    int l_t = first, l_j = 0, l_nt = cur.nt;               // weight-load cursor: tile, slab within the tile, channel tile
+    unsigned l_off = (unsigned)(l_nt * per_tile) * (unsigned)L::WSTAGE;
+    auto w_issue = [&](f32x4 (&set)[W_LOADS]) {
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) {
+        const int f = ptid + 256 * i;
+        ld16(set[i], rw, (f < W16 && l_t < end) ? l_off + (unsigned)f * 16u : HRSEG_BUF_OOB, 0);
+      }
+      l_off += L::WSTAGE;
+      if (++l_j == per_tile) {
+        l_j = 0;
+        ++l_t;
+        if (++l_nt == ntn) { l_nt = 0; l_off = 0; }       // the image is channel tile after channel tile
+      }
+    };
+    auto w_put = [&](int wboff, const f32x4 (&set)[W_LOADS]) {
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) {
+        const int f = ptid + 256 * i;
+        if (f < W16) *reinterpret_cast<f32x4*>(lw + wboff + f * 16) = set[i];
+      }
+    };
+    // prologue: the first patch (loads waited for one by one), weight slabs 0 and 1 into LDS, then slabs 2..5 in
+    // flight with the steady-state pattern (each followed by GPS patch loads, dummies here)
+    {
+      f32x4 v;
+      const i32x4_t rx0 = image_rsrc(cur.b);
+#pragma unroll 1
+      for (int i = 0; i < P_LOADS; ++i) {
+        patch_load1(v, rx0, cur, 0, i, true);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+        patch_store1(v, i, 0);
+      }
+    }
+    w_issue(rw4[0]);
+    w_issue(rw4[1]);
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw4[0][i]), "+v"(rw4[1][i]));
+    w_put(0, rw4[0]);
+    w_put(L::WSTAGE, rw4[1]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      w_issue(rw4[(d + 2) % D]);
+#pragma unroll
+      for (int e = 0; e < GPS; ++e) patch_load1(rpg[(d + 2) % D][e], rw, cur, 0, 0, false);
+    }
+    __syncthreads();
+    int wb2 = 2 * L::WSTAGE;               // weight buffer of slab j+2
+    int s = 0, pb = 0;                     // in-stage slab of j, patch buffer of the current stage
+    int n_t = first, n_ks = 0;             // the stage after the current one
+    bool have_next = false;
+    Geom nxt = cur;
+    i32x4_t rxn = image_rsrc(cur.b);
+    auto stage_begin = [&]() {
+      if (++n_ks == nks) {
+        n_ks = 0;
+        ++n_t;
+        const int b = nxt.b;
+        tile_next(nxt);
+        if (nxt.b != b) rxn = image_rsrc(nxt.b);
+      }
+      have_next = n_t < end;
+    };
+    stage_begin();
+    for (int j = 0; j < total; j += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        // (the slab count is padded to a multiple of D; the consumers meet the padding's barriers too)
+        f32x4 (&wset)[W_LOADS] = rw4[(u + 2) % D];
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wset[i]) : "n"(WAIT_W));
+        if (j + u + 2 < total) w_put(wb2, wset);
+        w_issue(wset);
+        // rpg[(u+2)%D] holds the granules loaded four slabs ago (the prologue's dummies shift the ring by two)
+        f32x4 (&pset)[GPS] = rpg[(u + 2) % D];
+#pragma unroll
+        for (int e = 0; e < GPS; ++e) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pset[e]) : "n"(WAIT_P));
+#pragma unroll
+        for (int e = 0; e < GPS; ++e) {
+          const int ist = (s - D) * GPS + e;
+          if (have_next && s >= D && ist < P_LOADS) patch_store1(pset[e], ist, pb ^ 1);
+        }
+#pragma unroll
+        for (int e = 0; e < GPS; ++e) {
+          const int ild = s * GPS + e;
+          patch_load1(pset[e], rxn, nxt, n_ks, ild, have_next && ild < P_LOADS);
+        }
+        __syncthreads();
+        wb2 = (wb2 == 2 * L::WSTAGE) ? 0 : wb2 + L::WSTAGE;
+        if (++s == NSLAB) { s = 0; pb ^= 1; stage_begin(); }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummies before the wave ends
+  }
+}
+
+template <int NS, int TH, int WTN, int CS, int FLIP>
+__global__ __launch_bounds__(512) void igemm_patch_ws_kernel(IgemmArgs p, int ntotal) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchWsLds<NS, TH, WTN, CS>::BYTES];
+  const int chunk = (ntotal + gridDim.x - 1) / gridDim.x;
+  const int first = blockIdx.x * chunk;
+  igemm_patch_ws_body<NS, TH, WTN, CS, FLIP>(p, lds, first, min(first + chunk, ntotal));
+}
+
+// grouped form: every problem runs the wave-specialised body on its own range of persistent blocks (grp.tiles[g]
+// blocks for problem g, grp.ksplit[g] = its tile count), with its own channel tiling: kind 1 = 48 channels x 48-channel
+// K stages, 2 = 96 x 48, 3 = 64 x 64, 4 = 48 x 48 on 16-row tiles
+template <int FLIP>
+__global__ __launch_bounds__(512) void igemm_patch_ws_group_kernel(IgemmGroup grp) {
+  static_assert(SpPatchWsLds<4, 16, 3, 3>::BYTES >= SpPatchWsLds<4, 8, 4, 4>::BYTES &&
+                SpPatchWsLds<4, 16, 3, 3>::BYTES >= SpPatchWsLds<4, 8, 6, 3>::BYTES, "LDS of the largest variant");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchWsLds<4, 16, 3, 3>::BYTES];
+  int gi = 0;
+  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
+  const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
+  const int nblk = grp.tiles[gi], ntotal = grp.ksplit[gi];
+  const int chunk = (ntotal + nblk - 1) / nblk;
+  const int first = local * chunk, end = min(first + chunk, ntotal);
+  const int kind = grp.kind[gi];
+  if (kind == 1) igemm_patch_ws_body<4, 8, 3, 3, FLIP>(grp.a[gi], lds, first, end);
+  else if (kind == 2) igemm_patch_ws_body<4, 8, 6, 3, FLIP>(grp.a[gi], lds, first, end);
+  else if (kind == 3) igemm_patch_ws_body<4, 8, 4, 4, FLIP>(grp.a[gi], lds, first, end);
+  else igemm_patch_ws_body<4, 16, 3, 3, FLIP>(grp.a[gi], lds, first, end);
 }
 
 // grouped launch whose problems run either body (the parallel HRNet branches: the wide high-resolution

@@ -79,6 +79,7 @@ def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None):
 def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
     pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions)."""
+    _lib.ensure_scratch(x.device)
     B, Hi, Wi, Cin = x.shape
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
@@ -90,6 +91,7 @@ def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
 
 def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=None):
     """wt = weight_transpose(w): [Cin][k*k][Cout]."""
+    _lib.ensure_scratch(dy.device)
     B, Hi, Wi, Cin = x_shape
     if out is None:
         out = empty_nhwc(B, Hi, Wi, Cin, dy)
@@ -113,6 +115,7 @@ def _shape_array(shapes):
 
 def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
     """n independent convolutions (same k, s) in one launch when the library can group them"""
+    _lib.ensure_scratch(xs[0].device)
     outs, shapes = [], []
     for x, co in zip(xs, couts):
         B, Hi, Wi, Cin = x.shape
@@ -127,6 +130,7 @@ def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
 
 def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=None):
     """outs[i] None -> allocated (accumulate ignored)"""
+    _lib.ensure_scratch(dys[0].device)
     outs, acc, shapes = list(outs), list(accumulate), []
     for i, (dy, xs) in enumerate(zip(dys, x_shapes)):
         if outs[i] is None:

@@ -43,7 +43,7 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.abi_version() == _lib.ABI_VERSION == 6
     assert not any(n.startswith("hrseg_debug_") for n in decls), "experimental switches do not belong in the public header"
 
 
@@ -55,6 +55,10 @@ def test_invalid_arguments_are_reported_without_a_gpu():
     rc = lib.hrseg_conv_fwd(None, None, None, None, ctypes.byref(shape), None)
     assert rc == -1
     assert b"does not match" in lib.hrseg_last_error_string()
+    lib.hrseg_set_scratch.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert lib.hrseg_set_scratch(None, 0) == 0                      # detach: always fine
+    assert lib.hrseg_set_scratch(ctypes.c_void_p(4096), 1024) == -1 and b"at least 1 MiB" in lib.hrseg_last_error_string()
+    assert lib.hrseg_set_scratch(ctypes.c_void_p(4097), 1 << 20) == -1 and b"aligned" in lib.hrseg_last_error_string()
     lib.hrseg_tune.argtypes = [ctypes.c_char_p, ctypes.c_int]
     assert lib.hrseg_tune(b"igemm_wtm", 0) == 0
     assert lib.hrseg_tune(b"no_such_knob", 1) == -1 and b"unknown key" in lib.hrseg_last_error_string()

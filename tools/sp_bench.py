@@ -58,7 +58,7 @@ for name, ci, co, k, s, H, W in SHAPES:
     line = "%-22s %6.1f GF |" % (name, flops / 1e9)
     for mode in MODES:
         pr = _lib.CONV_PRECISION[mode]
-        gm = gmax_t if mode == "fp16x2" else None
+        gm = gmax_t if mode in ("fp16x2", "auto") else None
         out = []
         if "fwd" in WHAT:
             y = ops.conv_fwd(x, w, None, k, s, prec=pr)
@@ -94,7 +94,7 @@ if not only or "group" in only:
             e = max(err(a, b) for a, b in zip(ys, base))
             t = timeit(lambda: ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n], prec=pr))
             dws = [torch.zeros_like(w) for w in ws[:n]]
-            gms = [d.abs().max().reshape(1).repeat(64) for d in dys[:n]] if mode == "fp16x2" else None
+            gms = [d.abs().max().reshape(1).repeat(64) for d in dys[:n]] if mode in ("fp16x2", "auto") else None
             tw = timeit(lambda: ops.conv_wgrad_group(xs[:n], dys[:n], dws, 3, 1, prec=pr, gmaxs=gms))
             print("group of %d branch convs  %-7s fwd %7.1f us %5.0f TF e=%.1e | wgrad %7.1f us %5.0f TF" % (
                 n, mode, t * 1e6, sum(fl[:n]) / t / 1e12, e, tw * 1e6, sum(fl[:n]) / tw / 1e12), flush=True)
