@@ -144,6 +144,27 @@ __device__ __forceinline__ f32x4 sp_mma(const bf16x8 (&w)[sp_np(NS)], const bf16
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc, 0, 0, 0);
 }
 
+// One product of sp_mma (pr = 0 .. sp_nprod(NS)-1, in sp_mma's order).  The kernels issue the products of a slab
+// product-outermost -- all accumulators' first product, then all second ones ... -- so that two MFMAs on the same
+// accumulator are never back to back: a dependent 16x16x32 MFMA waits for its predecessor's full latency (twice its
+// issue time), and the compiler keeps source order inside an unrolled slab.  Every accumulator still receives its
+// products in sp_mma's order, so results are bit-identical to the chained form.
+__host__ __device__ constexpr int sp_nprod(int ns) { return ns == 3 ? 6 : ns == 1 ? 1 : 3; }
+template <int NS>
+__device__ __forceinline__ f32x4 sp_mma_p(int pr, const bf16x8 (&w)[sp_np(NS)], const bf16x8 (&x)[sp_np(NS)], f32x4 acc) {
+  int wi = 0, xi = 0;
+  if (NS == 3) {
+    wi = (pr == 0 || pr == 3) ? 1 : (pr == 1) ? 2 : 0;
+    xi = (pr == 0 || pr == 4) ? 1 : (pr == 2) ? 2 : 0;
+  } else if (NS != 1) {
+    wi = pr == 0 ? 1 : 0;
+    xi = pr == 1 ? 1 : 0;
+  }
+  if (NS == 4)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[wi]), __builtin_bit_cast(f16x8, x[xi]), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[wi], x[xi], acc, 0, 0, 0);
+}
+
 template <int NS, int WTN>
 struct SpLds {
   static constexpr int BN = 16 * WTN;
@@ -312,7 +333,9 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
 #pragma unroll
         for (int q = 0; q < sp_np(NS); ++q) wf[q] = *reinterpret_cast<const bf16x8*>(base + q * PIECE + n * 1024 + foff);
 #pragma unroll
-        for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma<NS>(wf, xf[m], acc[n][m]);
+        for (int pr = 0; pr < sp_nprod(NS); ++pr)
+#pragma unroll
+          for (int m = 0; m < WTM; ++m) acc[n][m] = sp_mma_p<NS>(pr, wf, xf[m], acc[n][m]);
       }
       split_store((s + 1) & 1, ra[(d + 1) % D], rwt[(d + 1) % D]);      // slab s + 1
       __syncthreads();
@@ -509,7 +532,9 @@ __device__ __forceinline__ void wgrad_sp_body(const WgradArgs& p, unsigned char*
         afr[pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
       }
 #pragma unroll
-      for (int k = 0; k < TK; ++k) acc[n][k] = sp_mma<NS>(afr, bfr[k], acc[n][k]);
+      for (int pr = 0; pr < sp_nprod(NS); ++pr)
+#pragma unroll
+        for (int k = 0; k < TK; ++k) acc[n][k] = sp_mma_p<NS>(pr, afr, bfr[k], acc[n][k]);
     }
     __syncthreads();                       // every wave is done reading before the image is rewritten
     if (more) stage_store();
@@ -562,7 +587,9 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(WgradArgs p) {
 template <int NS, int TH, int WTN, int CS>
 struct SpPatchLds {
   static constexpr int PP = (TH + 2) * 18;              // patch pixels
-  static constexpr int CHUNK = PP * 32;                 // bytes per chunk image
+  // bytes per chunk image, padded to 64 mod 256: a 16-lane store group holds one pixel's granules of all CS chunks,
+  // and chunk images a multiple of 128 bytes apart would put chunks 0 and 2 on the same banks
+  static constexpr int CHUNK = PP * 32 + ((64 - (PP * 32) % 256) + 256) % 256;
   static constexpr int PPIECE = CS * CHUNK;             // per piece
   static constexpr int PATCH = sp_np(NS) * PPIECE;
   static constexpr int WPIECE = 16 * WTN * 64, WSTAGE = sp_np(NS) * WPIECE;
@@ -778,9 +805,11 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
         if (s == NSLAB - 3 && have_next) patch_load(nxt, nks_);          // in flight behind three slabs of MFMAs
         if (s + 1 < NSLAB) read_frags(s + 1, wb1, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
 #pragma unroll
-        for (int n = 0; n < WTN; ++n)
+        for (int pr = 0; pr < sp_nprod(NS); ++pr)
 #pragma unroll
-          for (int m = 0; m < RPW; ++m) acc[n][m] = sp_mma<NS>(wfr[s & 1][n], xfr[s & 1][m], acc[n][m]);
+          for (int n = 0; n < WTN; ++n)
+#pragma unroll
+            for (int m = 0; m < RPW; ++m) acc[n][m] = sp_mma_p<NS>(pr, wfr[s & 1][n], xfr[s & 1][m], acc[n][m]);
         if (s + 2 < NSLAB || have_next) w_store(wb2, s & 1);
         if (s == NSLAB - 1) {
           if (last_ks) { store_tile(cur); zero_acc(); }
@@ -1093,17 +1122,18 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     // prologue: the first patch (loads waited for one by one), weight slabs 0 and 1 into LDS, then slabs 2..5 in
     // flight with the steady-state pattern (each followed by GPS patch loads, dummies here)
     {
-      f32x4 v;
+      // all loads of the first patch and of weight slabs 0 and 1 in flight together: one L2 round trip, not one per granule
+      f32x4 v[P_LOADS];
       const i32x4_t rx0 = image_rsrc(cur.b);
-#pragma unroll 1
-      for (int i = 0; i < P_LOADS; ++i) {
-        patch_load1(v, rx0, cur, 0, i, true);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
-        patch_store1(v, i, 0);
-      }
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) patch_load1(v[i], rx0, cur, 0, i, true);
+      w_issue(rw4[0]);
+      w_issue(rw4[1]);
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]));
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) patch_store1(v[i], i, 0);
     }
-    w_issue(rw4[0]);
-    w_issue(rw4[1]);
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw4[0][i]), "+v"(rw4[1][i]));
     w_put(0, rw4[0]);
@@ -1334,9 +1364,11 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
             bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
           }
 #pragma unroll
-        for (int n = 0; n < TNK; ++n)
+        for (int pr = 0; pr < sp_nprod(NS); ++pr)
 #pragma unroll
-          for (int k = 0; k < TNK; ++k) acc[kw][n][k] = sp_mma<NS>(afr[n], bfr[k], acc[kw][n][k]);
+          for (int n = 0; n < TNK; ++n)
+#pragma unroll
+            for (int k = 0; k < TNK; ++k) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
       }
     }
   }

@@ -1,0 +1,176 @@
+"""The wave-specialised halo-patch kernels (csrc/conv_sp.h: igemm_patch_ws_body, sp_weight_image_kernel) through
+the C ABI.
+
+The wave-specialised body adds up the same products in the same order as the block-synchronous halo-patch body
+(same K stages, slabs and per-accumulator product order; the weights are split by the same function, once instead of
+per tile), so wherever both apply their results must be IDENTICAL bit for bit -- the strongest statement available,
+and the one asserted here; the fp32 torch-CPU convolution pins both within the fp16x2 tolerance (2e-5 of the
+reference's max magnitude).  Covered: every tiling (48, 96 and 64 output channels per tile, 8- and 16-row tiles),
+ragged image edges, one and several K stages, bias, accumulate, forward and data-gradient tap geometry, the grouped
+launch with its block partition, images whose tiles are mostly padding (20 x 20), the scratch ring wrapping around,
+and a scratch buffer too small for the weight image (the launch then takes the other kernel)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+# Cin, Cout, H, W, B, n48 (the 48-channel tilings are opt-in: hrseg_tune sp_ws_n48), exact: the block-synchronous
+# halo-patch body takes the same problem when the wave-specialised one is switched off (bit-identical results);
+# otherwise the im2col body does, whose reduction runs tap-major over all channels (same values to 2e-5)
+WS_CASES = [
+    (96, 96, 78, 78, 4, 0, True),       # 96-channel tiles, two K stages
+    (192, 192, 39, 39, 8, 0, False),    # four K stages, 26 % tile padding
+    (384, 384, 20, 20, 8, 0, False),    # eight K stages, tiles mostly padding
+    (64, 64, 70, 61, 6, 0, True),       # 64-channel tiles / 64-channel K stages, ragged edges
+    (128, 64, 62, 78, 5, 0, True),      # 64 x 64 tiling, two K stages
+    (128, 64, 57, 66, 4, 0, False),     # the same with 36 % tile padding
+    (48, 48, 155, 155, 2, 1, True),     # 48-channel tiles on 8-row tiles
+    (48, 48, 152, 155, 4, 1, True),     # 48-channel tiles on 16-row tiles
+    (96, 48, 37, 45, 13, 1, True),      # 48-channel tiles, two K stages, ragged edges
+    (48, 96, 46, 92, 6, 1, True),       # too few 96-channel tiles: 48-channel tiling of a 96-channel layer
+]
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+@pytest.fixture(autouse=True)
+def _restore_switches():
+    from hrseg_amd import _lib
+    yield
+    _lib.tune(sp_ws=1, sp_ws_n48=0)
+    _lib.set_deterministic(False)
+
+
+def _both(fn):
+    """fn() with the wave-specialised body enabled and disabled"""
+    from hrseg_amd import _lib
+    _lib.tune(sp_ws=1)
+    a = fn()
+    _lib.tune(sp_ws=0)
+    b = fn()
+    _lib.tune(sp_ws=1)
+    return a, b
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_ws_conv_bit_identical_to_block_synchronous_kernel_and_close_to_torch(case):
+    from hrseg_amd import _lib, ops
+    cin, cout, H, W, B, n48, exact = case
+    _lib.tune(sp_ws_n48=n48)
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, bias, stride=1, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd, wd, dyd, bd = _nhwc(x), w.permute(0, 2, 3, 1).contiguous().cuda(), _nhwc(dy), bias.cuda()
+    wt = ops.weight_transpose(wd.reshape(cout, 9, cin), cout, 9, cin)
+    gmax = dyd.abs().max().reshape(1).repeat(64)
+
+    y_ws, y_bs = _both(lambda: ops.conv_fwd(xd, wd.reshape(cout, 9, cin), bd, 3, 1, prec=pr))
+    assert not exact or torch.equal(y_ws, y_bs), "forward: wave-specialised and block-synchronous results differ"
+    assert _rel(y_ws, y_bs) < TOL
+    assert _rel(y_ws.permute(0, 3, 1, 2), y_ref) < TOL
+
+    dx_ws, dx_bs = _both(lambda: ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, prec=pr, gmax=gmax))
+    assert not exact or torch.equal(dx_ws, dx_bs), "data gradient: wave-specialised and block-synchronous results differ"
+    assert _rel(dx_ws, dx_bs) < TOL
+    assert _rel(dx_ws.permute(0, 3, 1, 2), xr.grad) < TOL
+
+    # accumulate: dx += on top of an existing gradient
+    base = torch.randn(xd.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    acc = ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, out=base.clone(), accumulate=True, prec=pr, gmax=gmax)
+    assert _rel((acc - base).permute(0, 3, 1, 2), xr.grad) < 2 * TOL
+
+
+def _branches(B, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    chans, sizes = [48, 96, 192, 384], [155, 78, 39, 20]
+    xs = [torch.randn(B, h, h, c, generator=g).cuda() for c, h in zip(chans, sizes)]
+    ws = [(torch.randn(c, 9, c, generator=g) / (9 * c) ** 0.5).cuda() for c in chans]
+    return chans, xs, ws
+
+
+@pytest.mark.parametrize("n48", [0, 1])
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_ws_group_launch_matches_single_launches(n, n48):
+    """the parallel HRNet branches as the engine issues them (one grouped call, `auto` arithmetic): whatever mix of
+    kernels the group dispatch picks, every branch must equal its own single fp16x2 launch"""
+    from hrseg_amd import _lib, ops
+    _lib.tune(sp_ws_n48=n48)
+    chans, xs, ws = _branches(8)            # the batch of the headline configuration: two level passes of four images
+    auto, f16 = _lib.CONV_PRECISION["auto"], _lib.CONV_PRECISION["fp16x2"]
+    ys = ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n], prec=auto)
+    for i in range(n):
+        single = ops.conv_fwd(xs[i], ws[i], None, 3, 1, prec=f16)
+        exact = ops.conv_fwd(xs[i], ws[i], None, 3, 1, prec=0)
+        assert _rel(ys[i], exact) < TOL, i
+        assert torch.equal(ys[i], single), f"branch {i}: grouped and single launches differ"
+    # data gradient of the same group
+    dys = [torch.randn_like(x) for x in xs[:n]]
+    wts = [ops.weight_transpose(w, c, 9, c) for w, c in zip(ws[:n], chans[:n])]
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    dxs = ops.conv_dgrad_group(dys, wts, [x.shape for x in xs[:n]], 3, 1, [None] * n, [False] * n, prec=auto, gmaxs=gms)
+    for i in range(n):
+        exact = ops.conv_dgrad(dys[i], wts[i], xs[i].shape, 3, 1, prec=0)
+        assert _rel(dxs[i], exact) < TOL, i
+
+
+def test_ws_is_bit_reproducible_and_independent_of_the_block_partition():
+    """no atomics, fixed summation order: repeated launches agree bit for bit, and so do a branch's results inside
+    groups of different sizes (different numbers of persistent blocks per problem)"""
+    from hrseg_amd import _lib, ops
+    chans, xs, ws = _branches(8, seed=9)
+    auto = _lib.CONV_PRECISION["auto"]
+    first = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=auto)
+    again = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=auto)
+    two = ops.conv_fwd_group(xs[2:], ws[2:], [None] * 2, 3, 1, chans[2:], prec=auto)
+    for i in range(4):
+        assert torch.equal(first[i], again[i])
+    for i in range(2):
+        assert torch.equal(first[i + 2], two[i])
+
+
+def test_scratch_ring_wraps_and_small_scratch_falls_back():
+    """weight images go through a ring in the caller's scratch buffer: launches with changing weights must each
+    see their own image after the ring has wrapped; a buffer too small for the image makes the launch take the
+    block-synchronous kernel (same bits)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 78, 78, 96, generator=g).cuda()
+    wlist = [(torch.randn(96, 9, 96, generator=g) / 30).cuda() for _ in range(7)]
+    _lib.tune(sp_ws=0)
+    want = [ops.conv_fwd(x, w, None, 3, 1, prec=pr) for w in wlist]
+    _lib.tune(sp_ws=1)
+    image_bytes = 96 * 9 * 96 * 4
+    try:
+        # four regions of 0.75 MiB: two images of 324 KiB fit, the third wraps
+        small = torch.empty(3 << 20, dtype=torch.uint8, device="cuda")
+        _lib.call_raw("hrseg_set_scratch", small.data_ptr(), small.numel())
+        assert (small.numel() // 4) // image_bytes == 2
+        for _ in range(3):
+            for w, y in zip(wlist, want):
+                assert torch.equal(ops.conv_fwd(x, w, None, 3, 1, prec=pr), y)
+        # 1 MiB: regions of 256 KiB cannot hold the image
+        tiny = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+        _lib.call_raw("hrseg_set_scratch", tiny.data_ptr(), tiny.numel())
+        assert torch.equal(ops.conv_fwd(x, wlist[0], None, 3, 1, prec=pr), want[0])
+        _lib.call_raw("hrseg_set_scratch", None, 0)
+        assert torch.equal(ops.conv_fwd(x, wlist[1], None, 3, 1, prec=pr), want[1])
+    finally:
+        torch.cuda.synchronize()
+        _lib._scratch = None            # ops re-attaches the default buffer at the next convolution
+        _lib.ensure_scratch(x.device)
