@@ -1266,9 +1266,12 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
   using L = SpWgrad9Lds<NS, TNK>;
   constexpr int S = L::S, PIECE = L::PIECE, XBASE = L::DYPIX * S;
   constexpr int GPP = TNK * 4;                               // 16-byte granules per pixel
-  constexpr int DYG = L::DYPIX * GPP, NG = (L::DYPIX + L::XPIX) * GPP;
-  constexpr int NT = 192, LOADS = (NG + NT - 1) / NT;
-  static_assert(NG >= NT, "spare lanes of the last round repeat a granule of the round before");
+  // a round of the block's 192 threads stages PR whole pixels (thread -> pixel tid / GPP of the round, granule
+  // tid % GPP of the pixel): the dy tile takes 64 / PR rounds -- one tile row each when PR = 16 -- and the x patch
+  // the rest; no division by a runtime value and one small multiply per granule (a wave issues an instruction every
+  // four cycles at best, and with 1.5 waves per SIMD the staging arithmetic is paid in MFMA time)
+  constexpr int NT = 192, PR = NT / GPP;
+  constexpr int DY_LOADS = (L::DYPIX + PR - 1) / PR, X_LOADS = (L::XPIX + PR - 1) / PR, LOADS = DY_LOADS + X_LOADS;
   const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;     // wave = kernel row
   const int g = lane >> 4, li = lane & 15;
   const int nkt = p.Cin / (16 * TNK);
@@ -1279,6 +1282,8 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
   sp_pow2_scale(p.dymax, dyscale, dyinv);
 
   f32x4 rg[LOADS];
+  const int pix0 = tid / GPP, gq = tid - pix0 * GPP;
+  const bool swork = pix0 < PR;                                // (TNK = 3: all 192 threads; TNK = 4: 12 x 16)
   auto tile_load = [&](int t) {
     const int tx = t % p.tiles_x;
     int r = t / p.tiles_x;
@@ -1287,38 +1292,35 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      int f = tid + NT * i;
-      if (f >= NG) f -= NT;
-      if (f < DYG) {
-        const int pix = f / GPP, q = f - pix * GPP;
-        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
-        const bool ok = (iy < p.H) & (ix < p.W);
-        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
-        rg[i] = buf_load4(rdy, off, 0);
-      } else {
-        const int fx = f - DYG;
-        const int pix = fx / GPP, q = fx - pix * GPP;
-        const int py = pix / 18, px = pix - py * 18;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
-        rg[i] = buf_load4(rx, off, 0);
-      }
+    for (int i = 0; i < DY_LOADS; ++i) {
+      const int pix = pix0 + PR * i;
+      const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
+      const bool ok = swork & (pix < L::DYPIX) & (iy < p.H) & (ix < p.W);
+      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+      rg[i] = buf_load4(rdy, off, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int pix = pix0 + PR * i;
+      const int py = (pix * 3641) >> 16, px = pix - py * 18;           // pix / 18
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = swork & (pix < L::XPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+      rg[DY_LOADS + i] = buf_load4(rx, off, 0);
     }
   };
   auto tile_store = [&]() {
+    // both images are [pixel][S bytes], the x patch behind the dy tile
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      int f = tid + NT * i;
-      if (f >= NG) f -= NT;
       u32x2 pc[sp_np(NS)];
-      sp_split4<NS>(rg[i], pc, f < DYG ? dyscale : 1.f);
-      // both images are [pixel][S bytes]: the x patch follows the dy tile, so granule f sits at pixel f / GPP
-      const int pix = f / GPP, q = f - pix * GPP;
-      const int o = pix * S + q * 8;
+      sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
+      const int pix = (i < DY_LOADS) ? pix0 + PR * i : L::DYPIX + pix0 + PR * (i - DY_LOADS);
+      const int o = pix * S + gq * 8;
+      if (swork && (i < DY_LOADS ? pix < L::DYPIX : pix < L::DYPIX + L::XPIX)) {
 #pragma unroll
-      for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + o) = pc[s];
+        for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lds + s * PIECE + o) = pc[s];
+      }
     }
   };
 
@@ -1341,9 +1343,13 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
     tile_store();
     if (t + 1 < t_hi) tile_load(t + 1);      // in flight behind this tile's MFMAs
     __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 afr[TNK][sp_np(NS)];
+    // Six groups (pixel half ks, kernel column kw) of TNK x TNK tiles.  Inside a group the products go output-channel
+    // block k outermost, so the x fragments of block k are dead after its TNK * products MFMAs and the reads of the
+    // NEXT group's block k can be issued into the same registers right there, behind the MFMAs still to come (pinned
+    // with sched_barrier: left alone the compiler bursts a group's reads in front of its MFMAs and every group starts
+    // with an exposed LDS round trip).  Only the dy fragments of the second pixel half are read in the open.
+    bf16x8 afr[TNK][sp_np(NS)], bfr[TNK][sp_np(NS)];
+    auto read_a = [&](int ks) {
 #pragma unroll
       for (int n = 0; n < TNK; ++n)
 #pragma unroll
@@ -1352,23 +1358,32 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
           const s16x4 v1 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * S + n * 32);
           afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
         }
+    };
+    auto read_b = [&](int grp, int k) {
+      const int ks = grp / 3, kw = grp % 3;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        bf16x8 bfr[TNK][sp_np(NS)];
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
+        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
+        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
+        bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+    };
+    read_a(0);
 #pragma unroll
-        for (int k = 0; k < TNK; ++k)
+    for (int k = 0; k < TNK; ++k) read_b(0, k);
 #pragma unroll
-          for (int pc = 0; pc < sp_np(NS); ++pc) {
-            const s16x4 v0 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
-            const s16x4 v1 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
-            bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-          }
+    for (int grp = 0; grp < 6; ++grp) {
+      const int kw = grp % 3;
+      if (grp == 3) read_a(1);
+#pragma unroll
+      for (int k = 0; k < TNK; ++k) {
 #pragma unroll
         for (int pr = 0; pr < sp_nprod(NS); ++pr)
 #pragma unroll
-          for (int n = 0; n < TNK; ++n)
-#pragma unroll
-            for (int k = 0; k < TNK; ++k) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
+          for (int n = 0; n < TNK; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + 1 < 6) read_b(grp + 1, k);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
