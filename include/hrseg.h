@@ -191,7 +191,7 @@ typedef struct {
   float* dres; int lddres; int dres_accumulate;      /* residual gradient (=|+=) g, or NULL         */
   long npix; int C;
   double* partial; int nchunks;                      /* scratch (nchunks+max(nseg,1))*2*C doubles   */
-  float* dy_absmax;                                  /* optional DEVICE array of 64 floats, zeroed by the caller:
+  float* dy_absmax;                                  /* optional DEVICE array of 64 floats (reset by the call):
                                                         slot (block % 64) receives the max|dy| of its blocks;
                                                         feeds hrseg_conv_shape_t.grad_absmax              */
   int nseg;                                          /* > 1: npix is nseg equal segments (the batched

@@ -766,6 +766,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   int local, nblk;
   const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
   const int nseg = p.nseg > 1 ? p.nseg : 1;
+  // the |dy| slots the apply kernel raises with atomicMax start from zero: reset here, two launches earlier on the stream
+  if (local == 0 && threadIdx.x < 64 && p.dy_absmax) p.dy_absmax[threadIdx.x] = 0.f;
   stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
              nseg);
 }

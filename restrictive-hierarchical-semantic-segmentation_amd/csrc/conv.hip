@@ -555,21 +555,30 @@ static size_t ws_image_bytes(const IgemmArgs& a, int kind) {
   const int wtn = WS_WTN[kind], cs = WS_CS[kind];
   return (size_t)(a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2) * (size_t)(2 * 16 * wtn * 64);
 }
-// writes the weight image of problem `a` (sets a.wimg); false: no scratch space
-static bool ws_make_image(IgemmArgs& a, int kind, hipStream_t st) {
-  unsigned char* img = scratch_alloc(st, ws_image_bytes(a, kind));
-  if (!img) return false;
-  const int wtn = WS_WTN[kind], cs = WS_CS[kind];
-  const dim3 grid((unsigned)((a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2)));
-  if (kind == 1 || kind == 4) hipLaunchKernelGGL((sp_weight_image_kernel<3, 3>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
-  else if (kind == 2) hipLaunchKernelGGL((sp_weight_image_kernel<6, 3>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
-  else hipLaunchKernelGGL((sp_weight_image_kernel<4, 4>), grid, dim3(256), 0, st, a.w, img, a.K, a.wscale);
-  a.wimg = img;
+// writes the weight images of n problems (sets a[i].wimg) with one launch; false: no scratch space
+static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st) {
+  WeightImageGroup g;
+  g.n = n;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    unsigned char* img = scratch_alloc(st, ws_image_bytes(a[i], kinds[i]));
+    if (!img) return false;
+    const int wtn = WS_WTN[kinds[i]], cs = WS_CS[kinds[i]];
+    end += (a[i].N / (16 * wtn)) * (a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
+    g.blk_end[i] = end;
+    g.kind[i] = kinds[i];
+    g.K[i] = a[i].K;
+    g.wscale[i] = a[i].wscale;
+    g.w[i] = a[i].w;
+    g.img[i] = img;
+    a[i].wimg = img;
+  }
+  hipLaunchKernelGGL(sp_weight_image_kernel, dim3(end), dim3(256), 0, st, g);
   return true;
 }
 static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
   const int ntotal = (int)ws_tiles(a, kind);
-  if (!ws_make_image(a, kind, st)) return 1;
+  if (!ws_make_images(&a, &kind, 1, st)) return 1;
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
@@ -617,8 +626,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     --blocks[lo];
     ++blocks[hi];
   }
-  for (int i = 0; i < n; ++i)
-    if (!ws_make_image(a[i], kinds[i], st)) return 1;
+  if (!ws_make_images(a, kinds, n, st)) return 1;
   int end = 0;
   for (int i = 0; i < n; ++i) {
     const int per = ceil_div((int)ntot[i], blocks[i]);

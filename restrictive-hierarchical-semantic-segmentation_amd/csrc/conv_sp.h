@@ -855,17 +855,18 @@ struct SpPatchWsLds {
   static constexpr int NSLAB = (9 * CS + 1) / 2;
 };
 
-// weight image: for every (channel tile, K stage, slab) the WSTAGE bytes the LDS weight buffer holds for it
+// weight image: for every (channel tile, K stage, slab) the WSTAGE bytes the LDS weight buffer holds for it; one
+// launch writes the images of all problems of a grouped launch
 template <int WTN, int CS>
-__global__ __launch_bounds__(256) void sp_weight_image_kernel(const float* __restrict__ w, unsigned char* __restrict__ img,
-                                                              int K, float wscale) {
+__device__ __forceinline__ void sp_weight_image_body(const float* __restrict__ w, unsigned char* __restrict__ img, int K,
+                                                     float wscale, int blk) {
   using L = SpPatchLds<4, 8, WTN, CS>;
   constexpr int BN = 16 * WTN, WG = BN * 8, NU = 9 * CS, NSLAB = (NU + 1) / 2;
   const int nks = K / (16 * CS);
-  const int slab = blockIdx.x % NSLAB;
-  const int ks = (blockIdx.x / NSLAB) % nks;
-  const int nt = blockIdx.x / (NSLAB * nks);
-  unsigned char* dst = img + (size_t)blockIdx.x * L::WSTAGE;
+  const int slab = blk % NSLAB;
+  const int ks = (blk / NSLAB) % nks;
+  const int nt = blk / (NSLAB * nks);
+  unsigned char* dst = img + (size_t)blk * L::WSTAGE;
   for (int f = threadIdx.x; f < WG; f += 256) {
     const int n = f >> 3, unit = (f >> 2) & 1, gq = f & 3;
     const int u = 2 * slab + unit;
@@ -880,6 +881,24 @@ __global__ __launch_bounds__(256) void sp_weight_image_kernel(const float* __res
     *reinterpret_cast<u32x2*>(dst + o) = pc[0];
     *reinterpret_cast<u32x2*>(dst + L::WPIECE + o) = pc[1];
   }
+}
+struct WeightImageGroup {
+  int n;
+  int blk_end[MAXG];
+  int kind[MAXG];          // channel tiling of the wave-specialised body (conv.hip: ws_kind)
+  int K[MAXG];
+  float wscale[MAXG];
+  const float* w[MAXG];
+  unsigned char* img[MAXG];
+};
+__global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g) {
+  int gi = 0;
+  while (gi + 1 < g.n && (int)blockIdx.x >= g.blk_end[gi]) ++gi;
+  const int blk = blockIdx.x - (gi ? g.blk_end[gi - 1] : 0);
+  const int kind = g.kind[gi];
+  if (kind == 2) sp_weight_image_body<6, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+  else if (kind == 3) sp_weight_image_body<4, 4>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+  else sp_weight_image_body<3, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
 }
 
 template <int NS, int TH, int WTN, int CS, int FLIP>

@@ -245,7 +245,7 @@ class Recorder:
         def bwd():
             bw = []
             # fp16x2: the BN backward records max|dy| per problem; the data / weight gradients scale dy by it
-            gmax_all = ops.zeros((n, 64), torch.float32, ys[0].device) if want_gmax else None
+            gmax_all = torch.empty((n, 64), dtype=torch.float32, device=ys[0].device) if want_gmax else None    # reset by bn_bwd
             gmaxs = [gmax_all[i] for i in range(n)] if want_gmax else [None] * n
             for i, ((x, conv, bn, res), y, z, coef) in enumerate(zip(items, ys, zs, coefs)):
                 dz = z.grad
