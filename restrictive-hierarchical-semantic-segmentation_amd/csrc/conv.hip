@@ -470,27 +470,6 @@ static int patch_cs(const IgemmArgs& a, int wtn) {
 static long patch_tiles(const IgemmArgs& a, int wtn) {
   return (long)a.B * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 16) * (a.N / (16 * wtn));
 }
-static int g_sp_persist = 2;            // hrseg_tune "sp_persist": persistent patch blocks per CU (0 = one tile per block)
-template <int NS>
-static int launch_patch_sp(const IgemmArgs& a, int wtn, int cs, hipStream_t st) {
-  const int ntotal = (int)patch_tiles(a, wtn);
-  int blocks = ntotal;
-  if (g_sp_persist > 0 && ntotal > 256 * g_sp_persist) {
-    // equal chunks: the block count that gives every block the same number of tiles (+-1)
-    const int per = ceil_div(ntotal, 256 * g_sp_persist);
-    blocks = ceil_div(ntotal, per);
-  }
-  const int flip = patch_flip(a);
-  const dim3 grid((unsigned)blocks);
-#define PS(N_, C_) if (wtn == N_ && cs == C_) { \
-    if (flip) hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 1>), grid, dim3(256), 0, st, a, ntotal); \
-    else hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 0>), grid, dim3(256), 0, st, a, ntotal); \
-    return 0; }
-  PS(3, 3) PS(3, 4) PS(4, 3) PS(4, 4) PS(6, 3) PS(6, 4)
-#undef PS
-  return 1;
-}
-
 // ---- wave-specialised halo-patch path (fp16x2; conv_sp.h: igemm_patch_ws_body)
 // The pre-split weight images live in a scratch buffer the host hands over once (hrseg_set_scratch; device memory is
 // the caller's, as everywhere in this ABI).  It is cut into four regions, one per stream that launches convolutions,
@@ -642,6 +621,33 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   return 0;
 }
 
+static int g_sp_img = 1;               // hrseg_tune "sp_img": 0 = the block-synchronous patch body splits its weights on the fly
+static int g_sp_persist = 2;            // hrseg_tune "sp_persist": persistent patch blocks per CU (0 = one tile per block)
+template <int NS>
+static int launch_patch_sp(const IgemmArgs& a_in, int wtn, int cs, hipStream_t st) {
+  const int ntotal = (int)patch_tiles(a_in, wtn);
+  int blocks = ntotal;
+  if (g_sp_persist > 0 && ntotal > 256 * g_sp_persist) {
+    // equal chunks: the block count that gives every block the same number of tiles (+-1)
+    const int per = ceil_div(ntotal, 256 * g_sp_persist);
+    blocks = ceil_div(ntotal, per);
+  }
+  const int flip = patch_flip(a_in);
+  const dim3 grid((unsigned)blocks);
+  IgemmArgs a = a_in;
+  if (NS == 4 && g_sp_img) {      // pre-split weights where an image layout exists for the tiling (else on the fly)
+    int kind = (wtn == 3 && cs == 3) ? 1 : (wtn == 6 && cs == 3) ? 2 : (wtn == 4 && cs == 4) ? 3 : 0;
+    if (kind) ws_make_images(&a, &kind, 1, st);      // (no scratch space: a.wimg stays null)
+  }
+#define PS(N_, C_) if (wtn == N_ && cs == C_) { \
+    if (flip) hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 1>), grid, dim3(256), 0, st, a, ntotal); \
+    else hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 0>), grid, dim3(256), 0, st, a, ntotal); \
+    return 0; }
+  PS(3, 3) PS(3, 4) PS(4, 3) PS(4, 4) PS(6, 3) PS(6, 4)
+#undef PS
+  return 1;
+}
+
 template <int NS>
 static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
 #define SP2(M_, N_) \
@@ -720,7 +726,16 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
 static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
 
 template <int NS>
-static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, int cs, hipStream_t st) {
+static int launch_sp_group(const IgemmGroup& g_in, int wtm, int wtn, int cs, hipStream_t st) {
+  IgemmGroup g = g_in;
+  if (NS == 4 && cs && g_sp_img && ((wtn == 3 && cs == 3) || (wtn == 4 && cs == 4))) {
+    IgemmArgs im[MAXG];
+    int kinds[MAXG], idx[MAXG], m = 0;
+    for (int i = 0; i < g.n; ++i)
+      if (g.kind[i]) { im[m] = g.a[i]; kinds[m] = wtn == 3 ? 1 : 3; idx[m++] = i; }
+    if (m && ws_make_images(im, kinds, m, st))
+      for (int j = 0; j < m; ++j) g.a[idx[j]].wimg = im[j].wimg;
+  }
   bool full = true;
   for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
   const dim3 grid(g.blk_end[g.n - 1]);
@@ -1752,7 +1767,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)

@@ -688,8 +688,24 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   }
   const bool wunit1 = (tid >> 2) & 1;        // (f>>2)&1 is the same for every i (256 is a multiple of 8)
   f32x4 rwt[2][W_LOADS];        // two slabs in flight: loaded a slab before they are split and stored
+  // p.wimg (fp16x2, set by the host when it has scratch space): the weights come pre-split, slab by slab in the
+  // layout of the LDS buffer (sp_weight_image_kernel), and are only copied -- the split of a weight slab is two
+  // thirds of this body's vector arithmetic, repeated for every tile
+  constexpr int W16 = NS == 4 ? L::WSTAGE / 16 : 0;        // (images exist for the two-piece fp16 split only)
+  static_assert(W16 <= 256 * W_LOADS, "a pre-split slab fits the register set of an fp32 one");
+  const bool img = NS == 4 && p.wimg != nullptr;
+  const __amdgpu_buffer_rsrc_t rwi = make_rsrc(reinterpret_cast<const float*>(p.wimg), (size_t)ntn * nks * NSLAB * L::WSTAGE);
   // weight slab `slab` (compile-time after unrolling) of K stage ks for channel tile n0 -> register set `set`
   auto w_load = [&](int n0, int ks, int slab, int set) {
+    if (img) {
+      const unsigned base = (unsigned)(((n0 / BN) * nks + ks) * NSLAB + slab) * (unsigned)L::WSTAGE;
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) {
+        const int f = tid + 256 * i;
+        rwt[set][i] = buf_load4(rwi, f < W16 ? base + (unsigned)f * 16u : HRSEG_BUF_OOB, 0);
+      }
+      return;
+    }
     const int uA = 2 * slab, uB = 2 * slab + 1;
     const int tA = uA / CS, cA = uA - tA * CS, tB = uB / CS, cB = uB - tB * CS;      // weight tap index = tap
     const unsigned col0 = (unsigned)(n0 * p.T * p.K + ks * CS * 16) * 4u;
@@ -704,6 +720,14 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   };
   auto w_store = [&](int wboff, int set) {
     unsigned char* base = lw + wboff;
+    if (img) {
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) {
+        const int f = tid + 256 * i;
+        if (f < W16) *reinterpret_cast<f32x4*>(base + f * 16) = rwt[set][i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
       u32x2 pc[sp_np(NS)];
