@@ -476,7 +476,7 @@ static long patch_tiles(const IgemmArgs& a, int wtn) {
 // each a ring: an image is written and read by kernels of ONE stream, in order, so reusing a slot after the ring
 // wraps needs no synchronisation.  Without a scratch buffer the path is simply not taken.
 static int g_sp_ws = 1;                 // hrseg_tune "sp_ws": 0 = never use the wave-specialised body
-static int g_ws_n48 = 0;                // hrseg_tune "sp_ws_n48": 0 = 48-channel tilings stay on the block-synchronous kernels
+static int g_ws_n48 = 1;                // hrseg_tune "sp_ws_n48": 0 = 48-channel tilings stay on the block-synchronous kernels
 static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile padding accepted, percent of the image
 static unsigned char* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;

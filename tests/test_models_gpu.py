@@ -116,7 +116,14 @@ def test_train_steps_track_the_oracle(name):
         assert abs(float(loss) - ref["loss"].item()) < TOL * abs(ref["loss"].item()), f"step {step}"
         vec = PT._metric_vectors(cms)
         for k, v in ref["metrics"].items():
-            assert np.allclose(vec[k].cpu().numpy(), v, atol=2e-3 if step == 0 else 1e-2), (step, k)
+            got = vec[k].cpu().numpy()
+            if step == 0:
+                assert np.allclose(got, v, atol=2e-3), (step, k)
+            else:
+                # after one AdamW step the two evaluations' weights differ by rounding noise (+-lr on elements whose
+                # gradient is noise, fp32 atomics in the default mode): a pixel at a decision boundary may flip, and
+                # one pixel of a 64 x 64 image moves a rare class's precision / recall by 1 / count
+                assert np.allclose(got, v, atol=3e-2) and np.abs(got - v).mean() < 6e-3, (step, k, got, v)
     # parameters after two AdamW steps
     osd = om.state_dict()
     for n, p in pm.state_dict().items():
