@@ -13,8 +13,9 @@ JSON line.  `python bench.py --gpus N` starts its own N ranks (torch.distributed
 process, before this process touches the GPU); under torchrun (WORLD_SIZE set) it is a rank itself.
 
 Extra objects in that line:
-  roofline     -- the dominant kernel (implicit-GEMM 3x3 conv 48->48 at 155x155, fp32 MFMA): algorithmic
-                  FLOPs per launch / average launch time measured here with events on the launch stream
+  roofline     -- the dominant kernel (wave-specialised halo-patch 3x3 convolution of the parallel HRNet branches,
+                  fp16x2 on the 16-bit matrix pipe): algorithmic FLOPs per launch / average launch time measured
+                  here with events on the launch stream; `roofline_other` the next kernel families
   cpu_baseline -- the CPU oracle (oracle/, a torch-CPU port of the reference path) timed on this host's
                   cores on a bounded sample (one batch-1 step); reported, never the target
 """
@@ -40,8 +41,13 @@ CONV_ARITHMETIC = {
               "fp32 accumulate (fp32-grade: the dropped cross terms are below 2^-24 relative)",
     "bf16x2": "fp32 operands split into 2 bf16 pieces, 3 products per tile on v_mfma_f32_16x16x32_bf16, fp32 "
               "accumulate (2^-16 relative operand error)",
-    "bf16": "operands rounded to bf16, one product on v_mfma_f32_16x16x32_bf16, fp32 accumulate"}
-CONV_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1}
+    "bf16": "operands rounded to bf16, one product on v_mfma_f32_16x16x32_bf16, fp32 accumulate",
+    "fp16x2": "fp32 operands split into 2 fp16 pieces (22 significant bits, power-of-two operand scaling), 3 products "
+              "per tile on v_mfma_f32_16x16x32_f16, fp32 accumulate (fp32-grade: ~1e-6 of the fp32 kernels' results)",
+    "auto": "fp32-grade throughout: fp16x2 (2 fp16 pieces per fp32 operand, 3 products on v_mfma_f32_16x16x32_f16, "
+            "fp32 accumulate) where it is the faster kernel family, exact-fp32 v_mfma_f32_16x16x4_f32 kernels on the "
+            "small problems; all weight gradients fp16x2"}
+CONV_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1, "fp16x2": 3, "auto": 3}
 TRAIN_GFLOP_PER_IMAGE = {          # BASELINE.md section 2 (conv+linear MACs x2, fwd+dgrad+wgrad = 3x fwd), 620x620
     ("hrnet", True): 1662.0, ("hrnet", False): 831.0, ("unet", True): 2168.0, ("unet", False): 1084.0}
 
@@ -125,11 +131,11 @@ def _timed(fn, reps=20):
 
 def probe_dominant_kernel(device, batch, size, conv_dtype="auto"):
     """The kernel with the largest share of the step.
-    conv_dtype 'auto' / 'fp16x2' (default): igemm_sp_pgroup_kernel<fp16x2>, the halo-patch launch of the two
-    high-resolution HRNet branches (3x3 convs, 48 ch at size/4 and 96 ch at size/8) -- every BasicBlock conv of stages
-    2-4 issues one forward and one data-gradient launch of it (64 + 64 per backbone pass).  Timed here with events on
-    the launch stream.  `achieved` = ALGORITHMIC FLOPs (2*M*N*K per branch) / launch time; every fp32-grade product
-    costs three fp16 MFMA products, so `peak` = dense fp16 MFMA peak / 3 and `frac` = executed MFMA rate / 2.5 PFLOP/s.
+    conv_dtype 'auto' / 'fp16x2' (default): igemm_patch_ws_group_kernel<fp16x2>, the wave-specialised halo-patch
+    launch of the parallel HRNet branches (3x3 convs, 48 ch at size/4 ... 384 ch at size/32) -- every BasicBlock conv
+    of stages 2-4 issues one forward and one data-gradient launch of it (64 + 64 per backbone pass).  Timed here with
+    events on the launch stream.  `achieved` = ALGORITHMIC FLOPs (2*M*N*K per branch) / launch time; every fp32-grade
+    product costs three fp16 MFMA products, so `peak` = dense fp16 MFMA peak / 3 and `frac` = executed MFMA rate / 2.5 PFLOP/s.
     conv_dtype 'f32': igemm_group_kernel on v_mfma_f32_16x16x4_f32 (stage-2/3/4 forward mix), peak 157.3."""
     from hrseg_amd import _lib, ops
     sizes, chans, xs, ws, fl = _branch_tensors(device, batch, size)
@@ -150,30 +156,42 @@ def probe_dominant_kernel(device, batch, size, conv_dtype="auto"):
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)",
                 "traffic_source": src, "avg_launch_us": round(t * 1e6, 2), "flop_per_launch": flops}
-    pr = _lib.CONV_PRECISION["fp16x2"]
-    t = _timed(lambda: ops.conv_fwd_group(xs[:2], ws[:2], [None, None], 3, 1, chans[:2], prec=pr), 50)
-    flops = fl[0] + fl[1]
+    # auto / fp16x2: the wave-specialised halo-patch group launch.  One backbone pass issues it once per BasicBlock conv
+    # of stages 2-4: 8 launches on the two high-resolution branches, 32 on three, 24 on all four -- timed here as that
+    # mix, as the engine issues it (`auto`), each launch preceded by its weight-image kernel (about 5 us, included)
+    pr = _lib.CONV_PRECISION["auto"]
+    mix = [(2, 8), (3, 32), (4, 24)]
+
+    def one_pass():
+        for n, reps in mix:
+            for _ in range(reps):
+                ops.conv_fwd_group(xs[:n], ws[:n], [None] * n, 3, 1, chans[:n], prec=pr)
+    launches = sum(r for _, r in mix)
+    t = _timed(one_pass, 5) / launches
+    flops = sum(sum(fl[:n]) * r for n, r in mix) / launches
     ach = flops / t / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-    name = "igemm_sp_pgroup_kernel<4, 2, 3, 3, 0>"
+    name = "igemm_patch_ws_group_kernel<0>"
     traffic, src = pmc_value(name, "traffic")
     busy, bsrc = pmc_value(name, "mfma_busy")
     return {"bound": "mfma",
-            "kernel": "igemm_sp_pgroup_kernel<fp16x2> (halo-patch 3x3 convs of the two high-resolution branches: 48 ch at %d, "
-                      "96 ch at %d, B=%d; forward launch, the data gradient runs the same kernel)" % (sizes[0], sizes[1], batch),
+            "kernel": "igemm_patch_ws_group_kernel<fp16x2> (wave-specialised halo-patch 3x3 convs of the parallel branches: "
+                      "%s ch at %s, B=%d; forward launches of one backbone pass -- 8 on two branches, 32 on three, 24 on four; "
+                      "the data gradient runs the same kernel)" % ("/".join(str(c) for c in chans), "/".join(str(h) for h in sizes), batch),
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMA products per fp32-grade product (fp16x2 split)",
             "executed_mfma_tflops": round(3 * ach, 1), "algorithmic_vs_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 3),
             "mfma_busy": busy, "mfma_busy_source": bsrc,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)", "traffic_source": src,
-            "avg_launch_us": round(t * 1e6, 2), "flop_per_launch": flops}
+            "avg_launch_us": round(t * 1e6, 2), "avg_launch_note": "launch = sp_weight_image_kernel + igemm_patch_ws_group_kernel",
+            "flop_per_launch": flops}
 
 
 def probe_secondary_kernels(device, batch, size, conv_dtype="auto"):
     """The next kernel families by time, measured the same way (events on the launch stream, algorithmic work over the
     measured duration): the grouped weight gradient of the four branch convs (auto: wgrad9_sp_group_kernel3<fp16x2> +
-    its ordered reduce), the full four-branch forward group as the model issues it (auto: one fp16x2 halo-patch launch
-    for the two high-resolution branches + the low-resolution branches' own launches), and the grouped BatchNorm
+    its ordered reduce), the full four-branch forward group as the model issues it (auto: one wave-specialised fp16x2
+    halo-patch launch for all four branches), and the grouped BatchNorm
     forward + backward of the four branches (HBM-bound; algorithmic bytes per element: statistics 4, apply 8, backward
     reduce 8, backward apply 12 -- no residual, ReLU mask recomputed from y)."""
     from hrseg_amd import _lib, ops
@@ -205,7 +223,7 @@ def probe_secondary_kernels(device, batch, size, conv_dtype="auto"):
          "achieved": round(total / t_w / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(total / t_w / 1e12 / peak, 4), "avg_launch_us": round(t_w * 1e6, 2)},
         {"bound": "mfma", "kernel": "four-branch forward group as issued (%s), B=%d" % (
-            "fp16x2 halo-patch launch + low-resolution launches" if f16 else "igemm_group_kernel", batch),
+            "one wave-specialised fp16x2 halo-patch launch" if f16 else "igemm_group_kernel", batch),
          "achieved": round(total / t_g / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(total / t_g / 1e12 / peak, 4), "avg_us": round(t_g * 1e6, 2)},
         {"bound": "hbm", "kernel": "bn_{stats,finalize,apply}_group + bn_bwd_{reduce,finalize,apply}_group (four branches, B=%d)" % batch,
@@ -222,7 +240,7 @@ def pmc_value(kernel, what):
     -> (value, source) or (None, None)."""
     import csv
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    fname = {"traffic": "r02_pmc_traffic_per_launch.csv", "mfma_busy": "r02_pmc_mfma_busy.csv"}[what]
+    fname = {"traffic": "r02b_pmc_traffic_per_launch.csv", "mfma_busy": "r02b_pmc_mfma_busy.csv"}[what]
     try:
         for row in csv.DictReader(open(os.path.join(root, fname))):
             if row["kernel"].startswith(kernel):
