@@ -343,10 +343,22 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
   }
 
   // epilogue: lane holds channels n0+16n+4g..+3 of pixel row r16 of every tile
+  // (all reads -- bias, the values an accumulating launch adds to -- before the first store: a read behind every
+  // store is a memory round trip each, see igemm_patch_ws_body)
   const bool split = ks_n > 1;
+  float* yrows[WTM];
+  f32x4 add[WTM][WTN];
+#pragma unroll
+  for (int n = 0; n < WTN; ++n) {
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ks_idx == 0) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * g);
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) add[m][n] = bv;
+  }
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
     const int row = m0 + wave * 16 * WTM + 16 * m + r16;
+    yrows[m] = nullptr;
     if (row >= p.M) continue;
     size_t pix = row;
     if (!p.direct_out) {
@@ -355,18 +367,26 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
       const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
       pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
     }
-    float* yrow = p.y + pix * p.ldy;
+    yrows[m] = p.y + pix * p.ldy;
+    if (p.accumulate && !split) {
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrows[m] + n0 + 16 * n + 4 * g);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    float* yrow = yrows[m];
+    if (!yrow) continue;
 #pragma unroll
     for (int n = 0; n < WTN; ++n) {
       const int ch = n0 + 16 * n + 4 * g;
       f32x4 v = acc[n][m];
       if (NS == 4) v *= oscale;
-      if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      v += add[m][n];
       if (split) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
       } else {
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
         *reinterpret_cast<f32x4*>(yrow + ch) = v;
       }
     }
@@ -778,6 +798,25 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
       for (int m = 0; m < RPW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto store_tile = [&](const Geom& q) {
+    // all reads of the tile before its first store (see igemm_patch_ws_body)
+    f32x4 add[RPW][WTN];
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + q.n0 + 16 * n + 4 * g);
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) add[m][n] = bv;
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) {
+        const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+        if (oy >= H || ox >= W) continue;
+        const float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
+#pragma unroll
+        for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.n0 + 16 * n + 4 * g);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
       const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
@@ -785,12 +824,9 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
       float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
-        const int ch = q.n0 + 16 * n + 4 * g;
         f32x4 v = acc[n][m];
         if (NS == 4) v *= oscale;
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
-        *reinterpret_cast<f32x4*>(yrow + ch) = v;
+        *reinterpret_cast<f32x4*>(yrow + q.n0 + 16 * n + 4 * g) = v + add[m][n];
       }
     }
   };
@@ -1021,19 +1057,35 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
         for (int m = 0; m < RPW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_tile = [&](const Geom& q) {
+      // every read of the tile (bias, the values an accumulating launch adds to) is issued before the first store: for
+      // all the compiler knows a store may alias the next read, and a read behind every store is a memory round trip each
+      // (measured on the accumulating data-gradient launches of the step: 156 -> 140 us on average)
+      f32x4 add[RPW][WTN];
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + q.nt * BN + 16 * n + 4 * g);
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) add[m][n] = bv;
+      }
+      if (p.accumulate) {
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) {
+          const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+          if (oy >= H || ox >= W) continue;
+          const float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
+#pragma unroll
+          for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
         if (oy >= H || ox >= W) continue;
         float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
 #pragma unroll
-        for (int n = 0; n < WTN; ++n) {
-          const int ch = q.nt * BN + 16 * n + 4 * g;
-          f32x4 v = acc[n][m] * oscale;
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
-          *reinterpret_cast<f32x4*>(yrow + ch) = v;
-        }
+        for (int n = 0; n < WTN; ++n)
+          *reinterpret_cast<f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g) = acc[n][m] * oscale + add[m][n];
       }
     };
     bf16x8 xfr[2][RPW][NP], wfr[2][WTN][NP];
