@@ -178,11 +178,46 @@ def test_graphed_train_step_tracks_eager(name):
     # UNet: the trajectories stay within 2e-3.  HRNet at 64x64 (2x2-pixel lowest branch, BN over 8 samples) is
     # chaotic: three EAGER runs from the same weights differ by 3e-4 / 2.5e-3 / 3e-3 at steps 2 / 3 / 4 (atomics
     # reorder sums), so later replays are only required to track loosely; the first replay must match.
-    tols = [2e-3, 2e-3, 2e-3] if kind == "unet" else [5e-4, 1e-2, 3e-2]
+    # (first replay: 6.7e-4 was observed inside a full-suite run, 3e-4 is typical; the deterministic variant below
+    # is the exact statement)
+    tols = [2e-3, 2e-3, 2e-3] if kind == "unet" else [1.5e-3, 1e-2, 3e-2]
     for a, b, tol in zip(got, eager[1:], tols):
         assert abs(a - b) < tol * abs(b), (got, eager)
     sd = opt.state_dict()                       # torch.optim.AdamW's layout; replays advance the device step counter
     assert all(float(st["step"]) == 4.0 for st in sd["state"].values()) and len(sd["state"]) == len(list(m.parameters()))
+
+
+def test_graphed_train_step_matches_eager_in_deterministic_mode():
+    """with the single-adder reductions (hrseg_tune deterministic) the chaotic 64x64 HRNet case has no noise to hide
+    behind: three replays of the captured step must give the eager step's losses"""
+    from hrseg_amd import _lib
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    name = "hrnet_hier_tl_64"
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    num_classes = [int(v) for v in g["num_classes"]]
+    args = _args(kind, hier, num_classes, level_weights_for(tree_file, hier), batch)
+    x, target = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+
+    def make():
+        m = build_model(PM, kind, hier, tree, size).cuda()
+        m.train()
+        return m, PT.FusedAdamW(m, lr=[1e-4]), [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in num_classes]
+
+    _lib.set_deterministic(True)
+    try:
+        m, opt, fns = make()
+        eager = [float(PT.train_step(m, opt, x, target, fns, args, tree, [])[0]) for _ in range(4)]
+        m, opt, fns = make()
+        graphed = PT.GraphedTrainStep(m, opt, fns, args, tree, x, target, warmup=1)
+        got = [float(graphed(x, target)[0]) for _ in range(3)]
+    finally:
+        _lib.set_deterministic(False)
+    for a, b in zip(got, eager[1:]):
+        assert abs(a - b) <= 1e-6 * abs(b), (got, eager)
 
 
 def test_consistency_on_model_probabilities_is_differentiable():
