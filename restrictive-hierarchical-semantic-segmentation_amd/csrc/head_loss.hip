@@ -105,17 +105,70 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const int c = i / F, k = i - c * F;
     weff[i] = (c < Cout) ? w[c * F + k] * (gam ? gam[k] : 1.f) : 0.f;
   }
-  if (threadIdx.x < CO) {
-    const int c = threadIdx.x;
-    float s = (c < Cout && bias) ? bias[c] : 0.f;
-    if (gam && c < Cout)
-      for (int k = 0; k < F; ++k) s = fmaf(w[c * F + k], gam[F + k], s);
-    beff[c] = s;
+  // beff[c] = bias[c] + sum_k w[c][k] * beta[k]: all 256 threads take part (four threads walking F elements each was
+  // a 720-step serial chain at the head of every block: most of this kernel's time with FiLM on)
+  {
+    __shared__ float red[CO][4];
+    float part[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      part[c] = 0.f;
+      if (gam && c < Cout)
+        for (int k = threadIdx.x; k < F; k += 256) part[c] = fmaf(w[c * F + k], gam[F + k], part[c]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part[c] += __shfl_xor(part[c], o, 64);
+      if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = part[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < CO) {
+      const int c = threadIdx.x;
+      beff[c] = ((c < Cout && bias) ? bias[c] : 0.f) + ((red[c][0] + red[c][1]) + (red[c][2] + red[c][3]));
+    }
   }
   __syncthreads();
   constexpr int PPB = 256 / LP;  // pixels per block iteration
   const int sub = threadIdx.x % LP, pg = threadIdx.x / LP;
   const int Q = F >> 2;
+  if (Q <= 3 * LP) {
+    // a lane reads the same (at most three) 4-channel groups of every pixel: its slice of the effective weights lives
+    // in registers for the whole block, and the pixel loop is global loads + FMAs only (reading the weights from LDS
+    // per pixel was four ds_read_b128 per 16 bytes of features: 217 us for the 553 MB of the HRNet feature map)
+    f32x4 wr[3][CO];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const int q = sub + j * LP;
+        wr[j][c] = (q < Q) ? *reinterpret_cast<const f32x4*>(weff + c * F + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    for (long pix = (long)blockIdx.x * PPB + pg; pix < hw; pix += (long)gridDim.x * PPB) {
+      const float* row = f + ((size_t)b * hw + pix) * ldf;
+      f32x4 v[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int q = sub + j * LP;
+        v[j] = (q < Q) ? *reinterpret_cast<const f32x4*>(row + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float acc[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        acc[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[c] += v[j][0] * wr[j][c][0] + v[j][1] * wr[j][c][1] + v[j][2] * wr[j][c][2] + v[j][3] * wr[j][c][3];
+      }
+#pragma unroll
+      for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+      if (sub == 0) {
+        float* o = z + ((size_t)b * hw + pix) * ldz;
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+          if (c < Cout) o[c] = acc[c] + beff[c];
+      }
+    }
+    return;
+  }
   for (long pix = (long)blockIdx.x * PPB + pg; pix < hw; pix += (long)gridDim.x * PPB) {
     const float* row = f + ((size_t)b * hw + pix) * ldf;
     float acc[CO];
@@ -177,25 +230,45 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < CO; ++c)
       if (c < Cout) wq[c] = *reinterpret_cast<const f32x4*>(w + c * F + 4 * cq);
-    for (long pix = lo + pl; pix < hi; pix += P) {
-      const size_t r = (size_t)b * hw + pix;
-      const f32x4 fv = *reinterpret_cast<const f32x4*>(f + r * ldf + 4 * cq);
+    // four pixels per iteration, every load of the four before the arithmetic: with one channel group per thread and
+    // one pixel per iteration the loop had a single 16-byte load in flight per thread
+    constexpr int U = 4;
+    auto one = [&](const f32x4& fv, const float (&g)[CO], const f32x4& dold, size_t r) {
       const f32x4 fm = fv * gam + bet;
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < CO; ++c) {
-        const float g = (c < Cout) ? dz[r * lddz + c] : 0.f;
-        u += wq[c] * g;
-        a_dw[c] += fm * g;
-        if (cq == 0) a_bias[c] += g;
+        u += wq[c] * g[c];
+        a_dw[c] += fm * g[c];
+        if (cq == 0) a_bias[c] += g[c];
       }
       a_dg += fv * u;
       a_db += u;
-      if (df) {
-        float* d = df + r * lddf + 4 * cq;
-        const f32x4 o = gam * u;
-        *reinterpret_cast<f32x4*>(d) = df_acc ? *reinterpret_cast<const f32x4*>(d) + o : o;
+      if (df) *reinterpret_cast<f32x4*>(df + r * lddf + 4 * cq) = dold + gam * u;
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool racc = df && df_acc;
+    long pix = lo + pl;
+    for (; pix + (long)(U - 1) * P < hi; pix += (long)U * P) {
+      f32x4 fv[U], dold[U];
+      float g[U][CO];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const size_t r = (size_t)b * hw + pix + (long)i * P;
+        fv[i] = *reinterpret_cast<const f32x4*>(f + r * ldf + 4 * cq);
+        dold[i] = racc ? *reinterpret_cast<const f32x4*>(df + r * lddf + 4 * cq) : zero;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) g[i][c] = (c < Cout) ? dz[r * lddz + c] : 0.f;
       }
+#pragma unroll
+      for (int i = 0; i < U; ++i) one(fv[i], g[i], dold[i], (size_t)b * hw + pix + (long)i * P);
+    }
+    for (; pix < hi; pix += P) {
+      const size_t r = (size_t)b * hw + pix;
+      float g[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) g[c] = (c < Cout) ? dz[r * lddz + c] : 0.f;
+      one(*reinterpret_cast<const f32x4*>(f + r * ldf + 4 * cq), g, racc ? *reinterpret_cast<const f32x4*>(df + r * lddf + 4 * cq) : zero, r);
     }
   }
   // reduce over the pixel lanes of the block, then one atomic per (channel, output)
@@ -727,7 +800,8 @@ extern "C" int hrseg_head_fwd(const float* f, int ldf, const float* gb, const fl
   const size_t smem = (size_t)(co * F + co) * sizeof(float);
   const int lp = (F / 4 <= 16) ? 16 : 64;
   long blocks = (hw + (256 / lp) - 1) / (256 / lp);
-  if (blocks > 2048) blocks = 2048;
+  const long cap = (2048 + B - 1) / B < 64 ? 64 : (2048 + B - 1) / B;      // ~2048 blocks in all: the per-block set-up is paid once per CU slot
+  if (blocks > cap) blocks = cap;
   dim3 grid((int)blocks, B);
 #define HF(LP_, CO_) hipLaunchKernelGGL((head_fwd_kernel<LP_, CO_>), grid, dim3(256), smem, st, f, ldf, gb, w, bias, z, ldz, hw, F, Cout)
   if (lp == 16 && co == 4) HF(16, 4);
