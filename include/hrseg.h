@@ -118,10 +118,11 @@ int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* 
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
  * wgrad_group_min, wgrad_group_max (csrc/conv.hip, hrseg_tune).  Unknown key: HRSEG_ERR_INVALID_ARG. */
 int hrseg_tune(const char* key, int value);
-/* Scratch memory for the convolution launches (device, 256-byte aligned, at least 1 MiB; 64 MiB covers every layer
+/* Scratch memory for the convolution launches (device, 256-byte aligned, at least 1 MiB; 256 MiB covers every layer
  * of the reference's models): the wave-specialised fp16x2 kernels of the wide 3x3 stride-1 layers read their weights
- * from a pre-split image that a small kernel writes there right before each launch, on the same stream (up to four
- * streams get a region each).  The buffer stays the caller's and must outlive the launches; (NULL, 0) detaches it.
+ * from a pre-split image (4 bytes per weight) that a small kernel writes there right before each launch, on the same
+ * stream (up to eight streams get an eighth of the buffer each; a layer whose image does not fit its region, or a
+ * ninth stream, takes the block-synchronous kernels).  The buffer stays the caller's and must outlive the launches; (NULL, 0) detaches it.
  * Without it those layers run the block-synchronous kernels: same results, slower. */
 int hrseg_set_scratch(void* ptr, size_t bytes);
 /* wt[ci][t][co] = w[co][t][ci] */

@@ -139,7 +139,7 @@ def ensure_scratch(device):
     if _scratch is not None:
         return
     import torch
-    nbytes = int(os.environ.get("HRSEG_SCRATCH_MB", "64")) << 20
+    nbytes = int(os.environ.get("HRSEG_SCRATCH_MB", "256")) << 20
     if nbytes == 0:
         _scratch = False
         return

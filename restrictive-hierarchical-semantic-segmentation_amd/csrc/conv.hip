@@ -472,7 +472,7 @@ static long patch_tiles(const IgemmArgs& a, int wtn) {
 }
 // ---- wave-specialised halo-patch path (fp16x2; conv_sp.h: igemm_patch_ws_body)
 // The pre-split weight images live in a scratch buffer the host hands over once (hrseg_set_scratch; device memory is
-// the caller's, as everywhere in this ABI).  It is cut into four regions, one per stream that launches convolutions,
+// the caller's, as everywhere in this ABI).  It is cut into eight regions, one per stream that launches convolutions,
 // each a ring: an image is written and read by kernels of ONE stream, in order, so reusing a slot after the ring
 // wraps needs no synchronisation.  Without a scratch buffer the path is simply not taken.
 static int g_sp_ws = 1;                 // hrseg_tune "sp_ws": 0 = never use the wave-specialised body
@@ -481,7 +481,8 @@ static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile paddin
 static unsigned char* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 struct ScratchRegion { hipStream_t st; bool used; size_t head; };
-static ScratchRegion g_regions[4];
+static const int SCRATCH_REGIONS = 8;
+static ScratchRegion g_regions[SCRATCH_REGIONS];
 extern "C" int hrseg_set_scratch(void* ptr, size_t bytes) {
   HRSEG_CHECK_ARG((ptr && bytes >= (1u << 20)) || (!ptr && bytes == 0), "hrseg_set_scratch: need a buffer of at least 1 MiB, or (null, 0)");
   HRSEG_CHECK_ARG(((uintptr_t)ptr & 255) == 0, "hrseg_set_scratch: the buffer must be 256-byte aligned");
@@ -492,13 +493,13 @@ extern "C" int hrseg_set_scratch(void* ptr, size_t bytes) {
 }
 static unsigned char* scratch_alloc(hipStream_t st, size_t bytes) {
   if (!g_scratch) return nullptr;
-  const size_t region = (g_scratch_bytes / 4) & ~(size_t)255;
+  const size_t region = (g_scratch_bytes / SCRATCH_REGIONS) & ~(size_t)255;
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes > region) return nullptr;
   int r = -1;
-  for (int i = 0; i < 4 && r < 0; ++i)
+  for (int i = 0; i < SCRATCH_REGIONS && r < 0; ++i)
     if (g_regions[i].used && g_regions[i].st == st) r = i;
-  for (int i = 0; i < 4 && r < 0; ++i)
+  for (int i = 0; i < SCRATCH_REGIONS && r < 0; ++i)
     if (!g_regions[i].used) { g_regions[i] = ScratchRegion{st, true, 0}; r = i; }
   if (r < 0) return nullptr;
   if (g_regions[r].head + bytes > region) g_regions[r].head = 0;

@@ -157,14 +157,14 @@ def test_scratch_ring_wraps_and_small_scratch_falls_back():
     _lib.tune(sp_ws=1)
     image_bytes = 96 * 9 * 96 * 4
     try:
-        # four regions of 0.75 MiB: two images of 324 KiB fit, the third wraps
-        small = torch.empty(3 << 20, dtype=torch.uint8, device="cuda")
+        # eight regions of 0.75 MiB: two images of 324 KiB fit, the third wraps
+        small = torch.empty(6 << 20, dtype=torch.uint8, device="cuda")
         _lib.call_raw("hrseg_set_scratch", small.data_ptr(), small.numel())
-        assert (small.numel() // 4) // image_bytes == 2
+        assert (small.numel() // 8) // image_bytes == 2
         for _ in range(3):
             for w, y in zip(wlist, want):
                 assert torch.equal(ops.conv_fwd(x, w, None, 3, 1, prec=pr), y)
-        # 1 MiB: regions of 256 KiB cannot hold the image
+        # 1 MiB: regions of 128 KiB cannot hold the image
         tiny = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
         _lib.call_raw("hrseg_set_scratch", tiny.data_ptr(), tiny.numel())
         assert torch.equal(ops.conv_fwd(x, wlist[0], None, 3, 1, prec=pr), want[0])
