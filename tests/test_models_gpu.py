@@ -123,7 +123,8 @@ def test_train_steps_track_the_oracle(name):
                 # after one AdamW step the two evaluations' weights differ by rounding noise (+-lr on elements whose
                 # gradient is noise, fp32 atomics in the default mode): a pixel at a decision boundary may flip, and
                 # one pixel of a 64 x 64 image moves a rare class's precision / recall by 1 / count
-                assert np.allclose(got, v, atol=3e-2) and np.abs(got - v).mean() < 6e-3, (step, k, got, v)
+                # (the tight second-step statement is test_train_steps_track_the_oracle_at_256)
+                assert np.allclose(got, v, atol=5e-2) and np.abs(got - v).mean() < 1e-2, (step, k, got, v)
     # parameters after two AdamW steps
     osd = om.state_dict()
     for n, p in pm.state_dict().items():
