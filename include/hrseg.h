@@ -114,9 +114,13 @@ size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes)
 int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
                               const hrseg_conv_shape_t* shapes, void* workspace, size_t workspace_bytes,
                               hrseg_stream_t stream);
-/* tile-plan overrides for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
+/* tile-plan overrides and A/B switches for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
- * wgrad_group_min, wgrad_group_max (csrc/conv.hip, hrseg_tune).  Unknown key: HRSEG_ERR_INVALID_ARG. */
+ * wgrad_group_min, wgrad_group_max (fp32 kernels); sp_wtm, sp_wtn, sp_ksplit, sp_patch, sp_persist (split-precision
+ * kernels); sp_ws (0: never use the wave-specialised 3x3 kernels), sp_ws_n48 (0: 48-channel tilings stay on the
+ * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_img (0: block-synchronous kernels
+ * split their weights on the fly); wgrad9, wgrad9_blocks (nine-tap weight gradient); deterministic (1: single-adder
+ * reductions everywhere) -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
 int hrseg_tune(const char* key, int value);
 /* Scratch memory for the convolution launches (device, 256-byte aligned, at least 1 MiB; 256 MiB covers every layer
  * of the reference's models): the wave-specialised fp16x2 kernels of the wide 3x3 stride-1 layers read their weights
