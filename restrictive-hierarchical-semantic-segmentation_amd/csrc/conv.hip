@@ -20,324 +20,12 @@
 //    pixels, reduce through LDS and add into dW with fp32 atomics (dW holds
 //    the running gradient of the step, so the add IS the accumulation).
 //  * Cin <= 4 (the image layer): direct VALU kernels.
-#include "common.h"
-#include <string.h>
-#include <stdint.h>
-
-// ---------------------------------------------------------------------------
-struct IgemmArgs {
-  const float* x;     // input pixels  [B,Hi,Wi,K]  row stride ldx
-  const float* w;     // weights [N][T][K]
-  const float* bias;  // [N] or null
-  float* y;           // output [B,Hy,Wy,N] row stride ldy
-  int ldx, ldy;
-  int B, Hi, Wi, K;          // K = input channels of this GEMM
-  int Ho, Wo, N;             // iteration grid (GEMM rows = B*Ho*Wo), N = output channels
-  int M;                     // B*Ho*Wo
-  int sy, sx;                // input coord = o*s + off[t]
-  int Hy, Wy, oys, oxs, oy0, ox0;  // output pixel = (oy*oys+oy0, ox*oxs+ox0) in Hy x Wy
-  int ntaps;
-  unsigned long long offy_pk, offx_pk, wtap_pk;  // 4 bits per tap: off+8, off+8, weight tap
-  int T;                     // taps stored per weight row (1 or 9)
-  int accumulate;            // y += result
-  float rcp_hw, rcp_w;       // 1/(Ho*Wo), 1/Wo: exact index division for < 2^24 pixels (fdiv)
-  int direct_out;            // output grid == iteration grid: output pixel index = GEMM row
-  const float* xmax;         // fp16x2: device scalar max|x| of the pixel operand when it is a gradient (else null)
-  float wscale, wscale_inv;  // fp16x2: fixed power-of-two scale of the weight operand and its inverse (1 otherwise)
-  int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
-  const unsigned char* wimg; // wave-specialised patch body: pre-split weight image (sp_weight_image_kernel), else null
-};
-
-// exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for
-// tensors of 2^24 pixels or more) selects the plain integer division
-__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
-  if (rcp <= 0.f) return n / d;
-  int q = (int)((float)n * rcp);
-  const int r = n - q * d;
-  q += (r >= d) ? 1 : 0;
-  q -= (r < 0) ? 1 : 0;
-  return q;
-}
-
-// Global -> register staging goes through BUFFER loads (resource descriptor in SGPRs + one 32-bit
-// byte offset per lane) instead of flat global loads with 64-bit per-lane addresses: measured on
-// MI355X every vector-memory instruction issued next to an MFMA stream costs matrix-pipe time
-// (tools/ubench/mfma_vmem.hip: 6 global loads per 24 MFMAs 140 -> 103 TFLOP/s, as buffer loads
-// 115), and the conv kernels gain 10-13 % (tools/ubench/depth_lab.hip).  The descriptor's range
-// check also gives the zero padding for free: a lane outside the image uses offset 0xFFFFFFFF.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#define HRSEG_BUF_FLAGS 0x00020000      // raw buffer, 32-bit data format (gfx9 family word 3)
-#define HRSEG_BUF_OOB 0xFFFFFFFFu
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
-                                           (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), HRSEG_BUF_FLAGS);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_bytes) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff_bytes, 0));
-}
-
-// swizzle of the 16-byte slot inside a 64-byte LDS row so that every 16-lane
-// group of a ds_read_b128 fragment read hits 16 distinct slots of the bank row
-__device__ __forceinline__ int lds_slot(int row, int slot) { return slot ^ ((-(row >> 2)) & 3); }
-
-// WTM x WTN 16x16 tiles per wave (4 waves split the pixel tile), KC 16-channel chunks per stage.
-// LDS stage image: A [KC][BM][16 floats], B [KC][BN][16 floats]; two stages (double buffer).
-// DB = LDS buffers: 2 = double buffer (one barrier per stage), 1 = single buffer (two barriers,
-// half the LDS, so more blocks per CU).  gridDim.y > 1 = split-K over the stage list: partial
-// sums are added with fp32 atomics.
-template <int WTM, int WTN, int KC, int DB>
-__device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const int bid, const int nblk,
-                                           const int ks_idx, const int ks_n) {
-  constexpr int BM = 64 * WTM;  // pixels per block
-  constexpr int BN = 16 * WTN;  // channels per block
-  constexpr int A_ROWS = BM / 64;
-  constexpr int B_F4 = BN * 4 * KC;
-  constexpr int B_LOADS = (B_F4 + 255) / 256;
-  constexpr int STAGE = (BM + BN) * 16 * KC;  // floats per LDS buffer
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntn = p.N / BN;
-  const int wg = xcd_remap(bid, nblk);
-  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
-
-  // stage range of this block (split-K)
-  const int kchunks = p.K / (16 * KC);
-  const int nstages_all = p.ntaps * kchunks;
-  const int per = (nstages_all + ks_n - 1) / ks_n;
-  const int s_lo = ks_idx * per;
-  const int s_hi = min(s_lo + per, nstages_all);
-  const int nstages = s_hi - s_lo;
-
-  // buffer resources: the input is addressed relative to the first image this tile touches, so the
-  // 32-bit lane offsets only have to span the tile's own images (host-checked), not the tensor
-  const int hw = p.Ho * p.Wo;
-  const int b0 = m0 / hw;
-  const __amdgpu_buffer_rsrc_t rx =
-      make_rsrc(p.x + (size_t)b0 * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b0) * p.Hi * p.Wi * p.ldx * 4);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (size_t)p.N * p.T * p.K * 4);
-
-  // rows this thread stages: r = (tid>>2) + 64*i, 16-byte slot q = tid&3
-  const int q = tid & 3;
-  int rpix[A_ROWS], riy[A_ROWS], rix[A_ROWS];
-#pragma unroll
-  for (int i = 0; i < A_ROWS; ++i) {
-    const int m = m0 + (tid >> 2) + 64 * i;
-    if (m < p.M) {
-      const int b = fdiv(m, hw, p.rcp_hw);
-      const int rem = m - b * hw;
-      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
-      rpix[i] = (b - b0) * p.Hi * p.Wi;
-      riy[i] = oy * p.sy;
-      rix[i] = ox * p.sx;
-    } else {
-      rpix[i] = 0;
-      riy[i] = -(1 << 20);
-      rix[i] = 0;
-    }
-  }
-  // LDS store offsets (constant per thread)
-  int a_st[A_ROWS], b_st[B_LOADS], b_row[B_LOADS], b_col[B_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_ROWS; ++i) {
-    const int r = (tid >> 2) + 64 * i;
-    a_st[i] = r * 16 + 4 * lds_slot(r, q);
-  }
-#pragma unroll
-  for (int i = 0; i < B_LOADS; ++i) {
-    const int f = tid + 256 * i;
-    const int j = f / (BN * 4), rem = f - j * (BN * 4);
-    const int r = rem >> 2, qq = rem & 3;
-    b_row[i] = r;
-    b_col[i] = 16 * j + 4 * qq;
-    b_st[i] = BM * 16 * KC + (j * BN + r) * 16 + 4 * lds_slot(r, qq);
-  }
-
-  // current tap / chunk
-  int t = s_lo / kchunks, c = s_lo - t * kchunks;
-  unsigned aoff[A_ROWS], boff[B_LOADS];   // byte offsets into rx / rw; HRSEG_BUF_OOB reads zeros
-  auto set_tap = [&](int tap) {
-    const int oy = (int)((p.offy_pk >> (4 * tap)) & 15) - 8;
-    const int ox = (int)((p.offx_pk >> (4 * tap)) & 15) - 8;
-    const int wt = (int)((p.wtap_pk >> (4 * tap)) & 15);
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const int iy = riy[i] + oy, ix = rix[i] + ox;
-      const bool ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
-      aoff[i] = ok ? ((unsigned)(rpix[i] + iy * p.Wi + ix) * (unsigned)p.ldx + 4u * q) * 4u : HRSEG_BUF_OOB;
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-      boff[i] = (tid + 256 * i < B_F4)
-                    ? ((unsigned)((n0 + b_row[i]) * p.T + wt) * (unsigned)p.K + (unsigned)b_col[i]) * 4u
-                    : HRSEG_BUF_OOB;
-  };
-
-  f32x4 ra[A_ROWS][KC], rb[B_LOADS];
-  auto stage_load = [&]() {   // loads stage (t, c), then advances (t, c)
-    const int c0 = c * 16 * KC;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i)
-#pragma unroll
-      for (int j = 0; j < KC; ++j) ra[i][j] = buf_load4(rx, aoff[i], (c0 + 16 * j) * 4);
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) rb[i] = buf_load4(rw, boff[i], c0 * 4);
-    if (++c == kchunks) {
-      c = 0;
-      ++t;
-      if (t < p.ntaps) set_tap(t);
-    }
-  };
-  auto stage_store = [&](int buf) {
-    float* base = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i)
-#pragma unroll
-      for (int j = 0; j < KC; ++j) *reinterpret_cast<f32x4*>(base + j * BM * 16 + a_st[i]) = ra[i][j];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-      if (tid + 256 * i < B_F4) *reinterpret_cast<f32x4*>(base + b_st[i]) = rb[i];
-  };
-
-  // v_mfma_f32_16x16x4_f32 only reaches its issue rate with ~12 independent accumulators in
-  // flight (measured: 4 chains 95 TF, 12 chains 150 TF, tools/ubench/mfma_peak.hip), so the k-steps
-  // of a chunk go to KP separate partial accumulators per output tile, summed in the epilogue.
-  constexpr int KP = (WTM * WTN <= 3) ? 4 : (WTM * WTN <= 6) ? 2 : 1;
-  f32x4 acc[KP][WTN][WTM];
-#pragma unroll
-  for (int kp = 0; kp < KP; ++kp)
-#pragma unroll
-    for (int n = 0; n < WTN; ++n)
-#pragma unroll
-      for (int m = 0; m < WTM; ++m) acc[kp][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offset of this lane inside a 16-row tile
-  const int frow = lane & 15;
-  const int foff = frow * 16 + 4 * lds_slot(frow, lane >> 4);
-
-  if (nstages > 0) {
-    set_tap(t);
-    stage_load();
-    stage_store(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = s + 1 < nstages;
-    if (more) stage_load();
-    const float* base = lds + ((DB == 2) ? (s & 1) : 0) * STAGE;
-#pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      f32x4 xf[WTM], wf[WTN];
-#pragma unroll
-      for (int m = 0; m < WTM; ++m)
-        xf[m] = *reinterpret_cast<const f32x4*>(base + (j * BM + wave * 16 * WTM + 16 * m) * 16 + foff);
-#pragma unroll
-      for (int n = 0; n < WTN; ++n)
-        wf[n] = *reinterpret_cast<const f32x4*>(base + BM * 16 * KC + (j * BN + 16 * n) * 16 + foff);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int n = 0; n < WTN; ++n)
-#pragma unroll
-          for (int m = 0; m < WTM; ++m)
-            acc[k % KP][n][m] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][k], acc[k % KP][n][m], 0, 0, 0);
-    }
-    if (DB == 1) __syncthreads();  // every wave is done reading before the buffer is rewritten
-    if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
-    __syncthreads();
-  }
-
-  // epilogue: lane holds channels n0+16n+4g..+3 of pixel row (lane&15)
-  const int g = lane >> 4;
-  const bool split = ks_n > 1;
-#pragma unroll
-  for (int m = 0; m < WTM; ++m) {
-    const int row = m0 + wave * 16 * WTM + 16 * m + (lane & 15);
-    if (row >= p.M) continue;
-    size_t pix = row;
-    if (!p.direct_out) {
-      const int b = fdiv(row, hw, p.rcp_hw);
-      const int rem = row - b * hw;
-      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
-      pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
-    }
-    float* yrow = p.y + pix * p.ldy;
-#pragma unroll
-    for (int n = 0; n < WTN; ++n) {
-      const int ch = n0 + 16 * n + 4 * g;
-      f32x4 v = acc[0][n][m];
-#pragma unroll
-      for (int kp = 1; kp < KP; ++kp) v += acc[kp][n][m];
-      if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
-      if (split) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
-      } else {
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
-        *reinterpret_cast<f32x4*>(yrow + ch) = v;
-      }
-    }
-  }
-}
-
-template <int WTM, int WTN, int KC, int DB>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(IgemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[DB * (64 * WTM + 16 * WTN) * 16 * KC];
-  igemm_body<WTM, WTN, KC, DB>(p, lds, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
-}
-
-// Several independent convolutions (the parallel HRNet branches) in ONE grid: block ranges
-// [blk_end[g-1], blk_end[g]) belong to problem g, each with its own tile count and split-K factor.
-#define MAXG 8
-struct IgemmGroup {
-  int n;
-  int blk_end[MAXG];
-  int tiles[MAXG];   // m-tiles * n-tiles of problem g (its blocks = tiles * ksplit)
-  int ksplit[MAXG];
-  int kind[MAXG];    // split-precision groups: 1 = halo-patch body (3x3 stride 1 on a wide image), 0 = im2col body
-  IgemmArgs a[MAXG];
-};
-// weight-gradient problem (kernels further down)
-struct WgradArgs {
-  const float* x;   // [B,Hi,Wi,Cin] ldx
-  const float* dy;  // [B,Ho,Wo,Cout] lddy
-  float* dw;        // [Cout][T][Cin]
-  int ldx, lddy;
-  int B, Hi, Wi, Cin, Ho, Wo, Cout;
-  int M;            // B*Ho*Wo
-  int ks, stride, T;
-  int pix_per_block;  // multiple of the stage size
-  float rcp_hw, rcp_w;  // 1/(Ho*Wo), 1/Wo
-  const float* dymax;   // fp16x2: device scalar max|dy| (null: unscaled)
-};
-
+//
+// This file holds the dispatch (tile plans, kernel-family choice per problem) and the C ABI; the kernel families
+// and their launchers live in conv_f32.hip, conv_wgrad_f32.hip, conv_sp_im2col.hip, conv_sp_patch.hip,
+// conv_sp_pgroup.hip, conv_ws.hip and conv_wgrad_sp.hip (split for build time; conv_common.h declares the launchers).
+#include "conv_common.h"
 #include "conv_sp.h"
-
-// FULL3X3 is a call-site tag only (same code): groups of full 3x3 stride-1 problems -- the parallel branch
-// convs, forward and data-gradient, the dominant launches of a step -- get their own kernel symbol, so
-// profiles list them apart from the small fuse-path / parity-class groups.
-template <int WTM, int WTN, int KC, int DB, bool FULL3X3>
-__global__ __launch_bounds__(256) void igemm_group_kernel(IgemmGroup grp) {
-  __shared__ __attribute__((aligned(16))) float lds[DB * (64 * WTM + 16 * WTN) * 16 * KC];
-  int g = 0;
-  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
-  const int local = blockIdx.x - (g ? grp.blk_end[g - 1] : 0);
-  const int tiles = grp.tiles[g];
-  igemm_body<WTM, WTN, KC, DB>(grp.a[g], lds, local % tiles, tiles, local / tiles, grp.ksplit[g]);
-}
-
-template <int WTM, int WTN, int KC, int DB>
-static void launch_igemm(const IgemmArgs& a, int ksplit, hipStream_t st) {
-  constexpr int BM = 64 * WTM, BN = 16 * WTN;
-  const int grid = ceil_div(a.M, BM) * (a.N / BN);
-  hipLaunchKernelGGL((igemm_conv_kernel<WTM, WTN, KC, DB>), dim3(grid, ksplit), dim3(256), 0, st, a);
-}
-template <int WTM, int WTN, int KC, int DB>
-static void launch_igemm_group(const IgemmGroup& g, hipStream_t st) {
-  bool full = true;
-  for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
-  if (full) hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, true>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((igemm_group_kernel<WTM, WTN, KC, DB, false>), dim3(g.blk_end[g.n - 1]), dim3(256), 0, st, g);
-}
 
 // tuning overrides (hrseg_tune, 0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
 static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
@@ -351,8 +39,6 @@ static void zero_f32(float* p, size_t n, hipStream_t st) {
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
 }
-
-struct IgemmPlan { int wtm, wtn, kc, db, ksplit; };
 
 static IgemmPlan plan_igemm(const IgemmArgs& a) {
   IgemmPlan pl;
@@ -417,7 +103,6 @@ static int finalize_args(IgemmArgs& a) {
 
 // ---- split-precision plan: 128-pixel tiles for large problems, 64 otherwise; split-K under 256 blocks
 static int g_sp_wtm = 0, g_sp_wtn = 0, g_sp_ksplit = 0;      // hrseg_tune overrides (0 = automatic)
-struct SpPlan { int wtm, wtn, ksplit; };
 static SpPlan plan_sp(const IgemmArgs& a) {
   SpPlan pl;
   pl.wtn = (a.N % 48 == 0) ? 3 : (a.N % 64 == 0) ? 4 : (a.N % 32 == 0) ? 2 : 1;
@@ -553,7 +238,7 @@ static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     g.img[i] = img;
     a[i].wimg = img;
   }
-  hipLaunchKernelGGL(sp_weight_image_kernel, dim3(end), dim3(256), 0, st, g);
+  launch_weight_images(g, end, st);
   return true;
 }
 static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
@@ -562,13 +247,7 @@ static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
-#define WS1(K_, H_, N_, C_) if (kind == K_) { \
-    if (flip) hipLaunchKernelGGL((igemm_patch_ws_kernel<4, H_, N_, C_, 1>), grid, dim3(512), 0, st, a, ntotal); \
-    else hipLaunchKernelGGL((igemm_patch_ws_kernel<4, H_, N_, C_, 0>), grid, dim3(512), 0, st, a, ntotal); \
-    return 0; }
-  WS1(1, 8, 3, 3) WS1(2, 8, 6, 3) WS1(3, 8, 4, 4) WS1(4, 16, 3, 3)
-#undef WS1
-  return 1;
+  return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st);
 }
 // One launch for several problems: the 256 persistent blocks are divided among the problems in proportion to their
 // slab counts, then blocks move from the problem that finishes first to the one that finishes last while that helps.
@@ -617,15 +296,12 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     g.kind[i] = kinds[i];
     g.a[i] = a[i];
   }
-  if (flip) hipLaunchKernelGGL((igemm_patch_ws_group_kernel<1>), dim3(end), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL((igemm_patch_ws_group_kernel<0>), dim3(end), dim3(512), 0, st, g);
-  return 0;
+  return launch_ws_group_kernel(g, flip, st);
 }
 
 static int g_sp_img = 1;               // hrseg_tune "sp_img": 0 = the block-synchronous patch body splits its weights on the fly
 static int g_sp_persist = 2;            // hrseg_tune "sp_persist": persistent patch blocks per CU (0 = one tile per block)
-template <int NS>
-static int launch_patch_sp(const IgemmArgs& a_in, int wtn, int cs, hipStream_t st) {
+static int launch_patch_sp(int ns, const IgemmArgs& a_in, int wtn, int cs, hipStream_t st) {
   const int ntotal = (int)patch_tiles(a_in, wtn);
   int blocks = ntotal;
   if (g_sp_persist > 0 && ntotal > 256 * g_sp_persist) {
@@ -634,31 +310,16 @@ static int launch_patch_sp(const IgemmArgs& a_in, int wtn, int cs, hipStream_t s
     blocks = ceil_div(ntotal, per);
   }
   const int flip = patch_flip(a_in);
-  const dim3 grid((unsigned)blocks);
   IgemmArgs a = a_in;
-  if (NS == 4 && g_sp_img) {      // pre-split weights where an image layout exists for the tiling (else on the fly)
+  if (ns == 4 && g_sp_img) {      // pre-split weights where an image layout exists for the tiling (else on the fly)
     int kind = (wtn == 3 && cs == 3) ? 1 : (wtn == 6 && cs == 3) ? 2 : (wtn == 4 && cs == 4) ? 3 : 0;
     if (kind) ws_make_images(&a, &kind, 1, st);      // (no scratch space: a.wimg stays null)
   }
-#define PS(N_, C_) if (wtn == N_ && cs == C_) { \
-    if (flip) hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 1>), grid, dim3(256), 0, st, a, ntotal); \
-    else hipLaunchKernelGGL((igemm_patch_sp_kernel<NS, 8, N_, C_, 0>), grid, dim3(256), 0, st, a, ntotal); \
-    return 0; }
-  PS(3, 3) PS(3, 4) PS(4, 3) PS(4, 4) PS(6, 3) PS(6, 4)
-#undef PS
-  return 1;
+  return launch_patch_sp_kernel(ns, a, wtn, cs, flip, blocks, ntotal, st);
 }
 
-template <int NS>
-static int launch_sp(const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
-#define SP2(M_, N_) \
-  if (pl.wtm == M_ && pl.wtn == N_) { \
-    hipLaunchKernelGGL((igemm_sp_kernel<NS, M_, N_>), dim3(ceil_div(a.M, 64 * M_) * (a.N / (16 * N_)), pl.ksplit), dim3(256), 0, st, a); \
-    return 0; }
-#define SP1(M_) SP2(M_, 1) SP2(M_, 2) SP2(M_, 3) SP2(M_, 4) SP2(M_, 6)
-  SP1(1) SP1(2) SP1(4)
-#undef SP1
-#undef SP2
+static int launch_sp(int ns, const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
+  if (launch_sp_kernel(ns, a, pl, st) == 0) return 0;
   hrseg_set_error("igemm_sp: no kernel for plan wtm=%d wtn=%d", pl.wtm, pl.wtn);
   return HRSEG_ERR_UNSUPPORTED;
 }
@@ -699,24 +360,15 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
       if (kind && ws_tiles(a, kind) >= 96 && launch_ws_single(a, kind, st) == 0) return 0;
     }
     if (const int cs = patch_cs(a, pl.wtn)) {
-      const int rc = ns == 4 ? launch_patch_sp<4>(a, pl.wtn, cs, st) : ns == 3 ? launch_patch_sp<3>(a, pl.wtn, cs, st) : ns == 2 ? launch_patch_sp<2>(a, pl.wtn, cs, st) : launch_patch_sp<1>(a, pl.wtn, cs, st);
+      const int rc = launch_patch_sp(ns, a, pl.wtn, cs, st);
       if (rc == 0) return 0;
     }
     if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
-    return ns == 4 ? launch_sp<4>(a, pl, st) : ns == 3 ? launch_sp<3>(a, pl, st) : ns == 2 ? launch_sp<2>(a, pl, st) : launch_sp<1>(a, pl, st);
+    return launch_sp(ns, a, pl, st);
   }
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
-#define IG4(M_, N_, K_, D_) \
-  if (pl.wtm == M_ && pl.wtn == N_ && pl.kc == K_ && pl.db == D_) { launch_igemm<M_, N_, K_, D_>(a, pl.ksplit, st); return 0; }
-#define IG3(M_, N_, K_) IG4(M_, N_, K_, 1) IG4(M_, N_, K_, 2)
-#define IG2(M_, N_) IG3(M_, N_, 1) IG3(M_, N_, 2) IG3(M_, N_, 3)
-#define IG1(M_) IG2(M_, 1) IG2(M_, 2) IG2(M_, 3) IG2(M_, 4) IG2(M_, 6)
-  IG1(1) IG1(2) IG1(4)
-#undef IG1
-#undef IG2
-#undef IG3
-#undef IG4
+  if (launch_igemm_f32(a, pl, st) == 0) return 0;
   hrseg_set_error("igemm: no kernel for plan wtm=%d wtn=%d kc=%d db=%d", pl.wtm, pl.wtn, pl.kc, pl.db);
   return HRSEG_ERR_UNSUPPORTED;
 }
@@ -726,10 +378,9 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
 // caller fall back to per-problem launches (return 1).
 static int g_group_wtm = 0;     // tuning override of the grouped launches' pixel tile (0 = automatic, 1 = 64, 2 = 128 pixels)
 
-template <int NS>
-static int launch_sp_group(const IgemmGroup& g_in, int wtm, int wtn, int cs, hipStream_t st) {
+static int launch_sp_group(int ns, const IgemmGroup& g_in, int wtm, int wtn, int cs, hipStream_t st) {
   IgemmGroup g = g_in;
-  if (NS == 4 && cs && g_sp_img && ((wtn == 3 && cs == 3) || (wtn == 4 && cs == 4))) {
+  if (ns == 4 && cs && g_sp_img && ((wtn == 3 && cs == 3) || (wtn == 4 && cs == 4))) {
     IgemmArgs im[MAXG];
     int kinds[MAXG], idx[MAXG], m = 0;
     for (int i = 0; i < g.n; ++i)
@@ -739,7 +390,6 @@ static int launch_sp_group(const IgemmGroup& g_in, int wtm, int wtn, int cs, hip
   }
   bool full = true;
   for (int i = 0; i < g.n; ++i) full = full && g.a[i].ntaps == 9 && g.a[i].T == 9 && g.a[i].sy == 1 && g.a[i].oys == 1;
-  const dim3 grid(g.blk_end[g.n - 1]);
   if (cs) {      // at least one problem runs the halo-patch body (all of them with the same tap geometry)
     int flip = -1;
     for (int i = 0; i < g.n; ++i)
@@ -748,23 +398,9 @@ static int launch_sp_group(const IgemmGroup& g_in, int wtm, int wtn, int cs, hip
         if (flip >= 0 && f != flip) return 1;
         flip = f;
       }
-#define SPP(M_, N_, C_) \
-    if (wtm == M_ && wtn == N_ && cs == C_) { \
-      if (flip) hipLaunchKernelGGL((igemm_sp_pgroup_kernel<NS, M_, N_, C_, 1>), grid, dim3(256), 0, st, g); \
-      else hipLaunchKernelGGL((igemm_sp_pgroup_kernel<NS, M_, N_, C_, 0>), grid, dim3(256), 0, st, g); \
-      return 0; }
-    SPP(1, 3, 3) SPP(2, 3, 3) SPP(1, 4, 4) SPP(2, 4, 4)
-#undef SPP
-    return 1;
+    return launch_sp_pgroup_kernel(ns, g, wtm, wtn, cs, flip, st);
   }
-#define SPG(M_, N_) \
-  if (wtm == M_ && wtn == N_) { \
-    if (full) hipLaunchKernelGGL((igemm_sp_group_kernel<NS, M_, N_, true>), grid, dim3(256), 0, st, g); \
-    else hipLaunchKernelGGL((igemm_sp_group_kernel<NS, M_, N_, false>), grid, dim3(256), 0, st, g); \
-    return 0; }
-  SPG(1, 3) SPG(1, 4) SPG(1, 6) SPG(2, 3) SPG(2, 4) SPG(2, 6)
-#undef SPG
-  return 1;
+  return launch_sp_group_kernel(ns, g, wtm, wtn, full, st);
 }
 
 static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st);
@@ -891,17 +527,8 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     g.kind[o] = kind[i];
     g.a[o] = fa[i];
   }
-  if (ns) return ns == 4 ? launch_sp_group<4>(g, wtm, wtn, group_cs, st) : ns == 3 ? launch_sp_group<3>(g, wtm, wtn, group_cs, st) : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, group_cs, st) : launch_sp_group<1>(g, wtm, wtn, group_cs, st);
-  if (wtm == 2 && wtn == 3 && kc == 3) launch_igemm_group<2, 3, 3, 1>(g, st);
-  else if (wtm == 2 && wtn == 3) launch_igemm_group<2, 3, 1, 1>(g, st);
-  else if (wtm == 2) return 1;
-  else if (wtn == 3 && kc == 3) launch_igemm_group<1, 3, 3, 1>(g, st);
-  else if (wtn == 3 && kc == 2) launch_igemm_group<1, 3, 2, 1>(g, st);
-  else if (wtn == 3) launch_igemm_group<1, 3, 1, 1>(g, st);
-  else if (kc == 3) launch_igemm_group<1, 4, 3, 1>(g, st);
-  else if (kc == 2) launch_igemm_group<1, 4, 2, 1>(g, st);
-  else launch_igemm_group<1, 4, 1, 1>(g, st);
-  return 0;
+  if (ns) return launch_sp_group(ns, g, wtm, wtn, group_cs, st);
+  return launch_igemm_group_f32(g, wtm, wtn, kc, st);
 }
 
 // --------------------------------------------------------------------------- direct conv, Cin <= 4
@@ -1029,179 +656,10 @@ __global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* 
   }
 }
 
-// --------------------------------------------------------------------------- wgrad on MFMA
-
-// Block = (tap, 16*TN couts, 16*TK cins, pixel range).  PIX pixels per LDS stage; the 4 waves split
-// the stage's pixels (the MFMA k dimension), so each wave accumulates the full TN x TK tile set and
-// the block reduces across waves through LDS before the atomic add.
-// Staging: thread (r = tid>>2, q = tid&3) owns pixel rows r, r+64 and the 16-byte slot q of every
-// 16-channel chunk, so the pixel -> (b,oy,ox) decode is done once per row per stage.
-template <int TN, int TK, int PIX, int DB>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& p, float* lds, const int bx, int id) {
-  constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16);  // row strides with (stride % 32) == 16
-  constexpr int SB = 16 * TK + ((TK % 2) ? 0 : 16);
-  constexpr int ROWS = PIX / 64;                     // rows per thread
-  constexpr int STAGE = PIX * (SA + SB);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nct = p.Cout / (16 * TN), nkt = p.Cin / (16 * TK);
-  const int kt = id % nkt;
-  id /= nkt;
-  const int ct = id % nct;
-  const int tap = id / nct;
-  const int n0 = ct * 16 * TN, k0 = kt * 16 * TK;
-  const int pad = (p.ks - 1) / 2;
-  const int kh = tap / p.ks - pad, kw = tap % p.ks - pad;
-
-  const int lo = bx * p.pix_per_block;
-  const int hi = min(lo + p.pix_per_block, p.M);
-  const int nstages = (hi - lo + PIX - 1) / PIX;
-  const int q = tid & 3, r0 = tid >> 2;
-
-  // buffer resources relative to this block's pixel range (dy) / its first image (x): rows past the
-  // range and padding pixels read zeros through the descriptor's range check
-  const int hw = p.Ho * p.Wo;
-  const int b_lo = lo / hw;
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
-  const __amdgpu_buffer_rsrc_t rx =
-      make_rsrc(p.x + (size_t)b_lo * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b_lo) * p.Hi * p.Wi * p.ldx * 4);
-
-  f32x4 ra[ROWS][TN], rb[ROWS][TK];
-  auto stage_load = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      const int ml = s * PIX + r0 + 64 * i;          // row inside the block's range
-      const int m = lo + ml;
-      const bool ok = m < hi;
-      const unsigned dyo = ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * q)) * 4u : HRSEG_BUF_OOB;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) ra[i][j] = buf_load4(rdy, dyo, 64 * j);
-      const int b = fdiv(m, hw, p.rcp_hw);
-      const int rem = m - b * hw;
-      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
-      const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
-      const bool okx = ok & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
-      const unsigned xo =
-          okx ? ((unsigned)(((b - b_lo) * p.Hi + iy) * p.Wi + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * q)) * 4u
-              : HRSEG_BUF_OOB;
-#pragma unroll
-      for (int j = 0; j < TK; ++j) rb[i][j] = buf_load4(rx, xo, 64 * j);
-    }
-  };
-  auto stage_store = [&](int buf) {
-    float* a = lds + buf * STAGE;
-    float* b = a + PIX * SA;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      const int r = r0 + 64 * i;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(a + r * SA + 16 * j + 4 * q) = ra[i][j];
-#pragma unroll
-      for (int j = 0; j < TK; ++j) *reinterpret_cast<f32x4*>(b + r * SB + 16 * j + 4 * q) = rb[i][j];
-    }
-  };
-
-  constexpr int KP = (TN * TK <= 9) ? 2 : 1;     // independent accumulation chains, see igemm_body
-  f32x4 acc2[KP][TN][TK];
-#pragma unroll
-  for (int kp = 0; kp < KP; ++kp)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k) acc2[kp][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (nstages > 0) {
-    stage_load(0);
-    stage_store(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = s + 1 < nstages;
-    if (more) stage_load(s + 1);
-    const float* a = lds + ((DB == 2) ? (s & 1) : 0) * STAGE;
-    const float* b = a + PIX * SA;
-#pragma unroll
-    for (int ks4 = 0; ks4 < PIX / 16; ++ks4) {
-      const int row = wave * (PIX / 4) + ks4 * 4 + (lane >> 4);
-      float af[TN], bf[TK];
-#pragma unroll
-      for (int n = 0; n < TN; ++n) af[n] = a[row * SA + 16 * n + (lane & 15)];
-#pragma unroll
-      for (int k = 0; k < TK; ++k) bf[k] = b[row * SB + 16 * k + (lane & 15)];
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int k = 0; k < TK; ++k)
-          acc2[ks4 % KP][n][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[n], bf[k], acc2[ks4 % KP][n][k], 0, 0, 0);
-    }
-    if (DB == 1) __syncthreads();
-    if (more) stage_store((DB == 2) ? ((s + 1) & 1) : 0);
-    __syncthreads();
-  }
-
-  // cross-wave reduction: red[wave][tile][r*64 + lane]
-#pragma unroll
-  for (int n = 0; n < TN; ++n)
-#pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      f32x4 v = acc2[0][n][k];
-#pragma unroll
-      for (int kp = 1; kp < KP; ++kp) v += acc2[kp][n][k];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[((wave * TN + n) * TK + k) * 256 + r * 64 + lane] = v[r];
-    }
-  __syncthreads();
-  const int r = tid >> 6, l = tid & 63;
-#pragma unroll
-  for (int n = 0; n < TN; ++n)
-#pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      float v = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < 4; ++wv) v += lds[((wv * TN + n) * TK + k) * 256 + tid];
-      const int co = n0 + 16 * n + 4 * (l >> 4) + r;  // D row = 4*(lane>>4)+reg
-      const int ci = k0 + 16 * k + (l & 15);          // D col = lane&15
-      atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, v);
-    }
-}
-
-
-template <int TN, int TK, int PIX, int DB>
-struct WgradLds {
-  static constexpr int SA = 16 * TN + ((TN % 2) ? 0 : 16), SB = 16 * TK + ((TK % 2) ? 0 : 16);
-  static constexpr int STAGE = PIX * (SA + SB), RED = 4 * TN * TK * 256;
-  static constexpr int FLOATS = (DB * STAGE > RED) ? DB * STAGE : RED;
-};
-// Block order: the (tap, tile) blocks of ONE pixel range are consecutive in the XCD-remapped id, so
-// the taps that re-read the same dy / x rows run together on one XCD and hit its L2 (the PMC
-// counters showed 3.2x the algorithmic bytes fetched with the pixel range as the fast index).
-template <int TN, int TK, int PIX, int DB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[WgradLds<TN, TK, PIX, DB>::FLOATS];
-  const int tiles = gridDim.y, nblk = gridDim.x * gridDim.y;
-  const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
-  wgrad_body<TN, TK, PIX, DB>(p, lds, r / tiles, r % tiles);
-}
-struct WgradGroup {
-  int n;
-  int blk_end[MAXG];
-  int gx[MAXG];       // pixel-range blocks of problem g (its blocks = gx * tiles)
-  WgradArgs a[MAXG];
-};
-template <int TN, int TK, int PIX, int DB>
-__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup grp) {
-  __shared__ __attribute__((aligned(16))) float lds[WgradLds<TN, TK, PIX, DB>::FLOATS];
-  int g = 0;
-  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
-  const int lo = g ? grp.blk_end[g - 1] : 0;
-  const int nblk = grp.blk_end[g] - lo;
-  const int tiles = nblk / grp.gx[g];
-  const int r = xcd_remap(blockIdx.x - lo, nblk);
-  wgrad_body<TN, TK, PIX, DB>(grp.a[g], lds, r / tiles, r % tiles);
-}
 static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
 
 // host-side check behind the 32-bit buffer offsets of wgrad_body: one block's pixel range
-static int check_wgrad_span(const WgradArgs& a) {
+int check_wgrad_span(const WgradArgs& a) {
   const double imgs = (double)ceil_div(a.pix_per_block, a.Ho * a.Wo) + 1.0;
   if (imgs * a.Hi * a.Wi * (double)a.ldx * 4.0 >= 4294967296.0 || (double)a.pix_per_block * a.lddy * 4.0 >= 4294967296.0) {
     hrseg_set_error("wgrad: a block's pixel range (%d pixels) exceeds the 4 GB buffer-offset range", a.pix_per_block);
@@ -1210,41 +668,11 @@ static int check_wgrad_span(const WgradArgs& a) {
   return 0;
 }
 
-template <int TN, int TK, int PIX, int DB>
-static int launch_wgrad_cfg(WgradArgs a, int target_blocks, hipStream_t st) {
-  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
-  int ksplit = target_blocks / tiles;
-  if (ksplit < 1 || hrseg_g_deterministic) ksplit = 1;       // deterministic: one pixel range, one adder per element
-  int ppb = ceil_div(ceil_div(a.M, ksplit), PIX) * PIX;
-  if (ppb < 4 * PIX) ppb = 4 * PIX;
-  a.pix_per_block = ppb;
-  if (int e = check_wgrad_span(a)) return e;
-  const int gx = ceil_div(a.M, ppb);
-  hipLaunchKernelGGL((wgrad_kernel<TN, TK, PIX, DB>), dim3(gx, tiles), dim3(256), 0, st, a);
-  return 0;
-}
-
-template <int TN, int TK>
-static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
-  // measured (tools/wgrad_sweep.py): 64-pixel stages, single LDS buffer; grid of ~7 blocks per
-  // output tile set, between 2 and 16 blocks per CU
-  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
-  int pix = 64, db = 1, target = 7 * tiles;
-  if (target < 512) target = 512;
-  if (target > 4096) target = 4096;
-  if (g_tune_wg_pix) pix = g_tune_wg_pix;
-  if (g_tune_wg_db) db = g_tune_wg_db;
-  if (g_tune_wg_blocks) target = g_tune_wg_blocks;
-  if (pix == 64 && db == 1) return launch_wgrad_cfg<TN, TK, 64, 1>(a, target, st);
-  if (pix == 64) return launch_wgrad_cfg<TN, TK, 64, 2>(a, target, st);
-  if (db == 1) return launch_wgrad_cfg<TN, TK, 128, 1>(a, target, st);
-  return launch_wgrad_cfg<TN, TK, 128, 2>(a, target, st);
-}
-
-template <int NS, int TN, int TK>
-static int launch_wgrad_sp(WgradArgs a, hipStream_t st) {
-  constexpr int PIX = SpWgradLds<NS, TN, TK>::PIX;
-  const int tiles = (a.Cout / (16 * TN)) * (a.Cin / (16 * TK)) * a.T;
+static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
+  const int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+  const int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
+  constexpr int PIX = 128;                      // SpWgradLds::PIX
+  const int tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
   int target = 7 * tiles;
   if (target < 512) target = 512;
   if (target > 4096) target = 4096;
@@ -1256,18 +684,7 @@ static int launch_wgrad_sp(WgradArgs a, hipStream_t st) {
   a.pix_per_block = ppb;
   if (int e = check_wgrad_span(a)) return e;
   const int gx = ceil_div(a.M, ppb);
-  hipLaunchKernelGGL((wgrad_sp_kernel<NS, TN, TK>), dim3(gx, tiles), dim3(256), 0, st, a);
-  return 0;
-}
-template <int NS>
-static int dispatch_wgrad_sp(const WgradArgs& a, hipStream_t st) {
-  int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
-  int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
-#define WS(TN_, TK_) if (tn == TN_ && tk == TK_) return launch_wgrad_sp<NS, TN_, TK_>(a, st);
-  WS(1, 1) WS(1, 2) WS(1, 3) WS(1, 4) WS(2, 1) WS(2, 2) WS(2, 3) WS(2, 4)
-  WS(3, 1) WS(3, 2) WS(3, 3) WS(3, 4) WS(4, 1) WS(4, 2) WS(4, 3) WS(4, 4)
-#undef WS
-  return HRSEG_ERR_UNSUPPORTED;
+  return launch_wgrad_sp_kernel(ns, a, tn, tk, gx, tiles, st);
 }
 
 static int g_wg_mult = 0, g_wg_min = 0, g_wg_max = 0;      // tuning overrides of the grouped weight-gradient grid
@@ -1307,10 +724,7 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
     g.blk_end[i] = end;
     g.a[i] = a[i];
   }
-#define WGG(TN_, TK_) if (tn == TN_ && tk == TK_) hipLaunchKernelGGL((wgrad_group_kernel<TN_, TK_, 64, 1>), dim3(end), dim3(256), 0, st, g);
-  WGG(3, 3) WGG(3, 4) WGG(4, 3) WGG(4, 4)
-#undef WGG
-  return 0;
+  return launch_wgrad_group_f32(g, tn, tk, end, st);
 }
 
 // --------------------------------------------------------------------------- nine-tap weight gradient (workspace + ordered reduce)
@@ -1373,15 +787,7 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
     r.blk_end[i] = rend;
     ws += (size_t)a.nchunks * elems;
   }
-#define W9(NS_) if (ns == NS_) { \
-    if (tnk == 3) hipLaunchKernelGGL((wgrad9_sp_group_kernel3<NS_>), dim3(end), dim3(192), 0, st, g); \
-    else hipLaunchKernelGGL((wgrad9_sp_group_kernel4<NS_>), dim3(end), dim3(192), 0, st, g); }
-  W9(1) W9(2) W9(3) W9(4)
-#undef W9
-  HRSEG_LAUNCH_CHECK("wgrad9");
-  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rend), dim3(256), 0, st, r);
-  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
-  return 0;
+  return launch_wgrad9_kernels(ns, tnk, g, end, r, rend, st);
 }
 
 // --------------------------------------------------------------------------- weight transpose
@@ -1727,16 +1133,24 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   a.rcp_w = big ? 0.f : 1.0f / (float)s->Wo;
   a.dymax = s->precision == HRSEG_CONV_FP16X2 ? s->grad_absmax : nullptr;
   if (const int ns = sp_pieces(s->precision)) {
-    if (int e = ns == 4 ? dispatch_wgrad_sp<4>(a, st) : ns == 3 ? dispatch_wgrad_sp<3>(a, st) : ns == 2 ? dispatch_wgrad_sp<2>(a, st) : dispatch_wgrad_sp<1>(a, st)) return e;
+    if (int e = dispatch_wgrad_sp(ns, a, st)) return e;
     HRSEG_LAUNCH_CHECK("wgrad_sp");
     return 0;
   }
   const int tn = (s->Cout % 48 == 0) ? 3 : (s->Cout % 64 == 0) ? 4 : (s->Cout % 32 == 0) ? 2 : 1;
   const int tk = (s->Cin % 48 == 0) ? 3 : (s->Cin % 64 == 0) ? 4 : (s->Cin % 32 == 0) ? 2 : 1;
-#define WG(TN_, TK_) if (tn == TN_ && tk == TK_) { if (int e = launch_wgrad<TN_, TK_>(a, st)) return e; }
-  WG(1, 1) WG(1, 2) WG(1, 3) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 3) WG(2, 4)
-  WG(3, 1) WG(3, 2) WG(3, 3) WG(3, 4) WG(4, 1) WG(4, 2) WG(4, 3) WG(4, 4)
-#undef WG
+  {
+    // measured (tools/wgrad_sweep.py): 64-pixel stages, single LDS buffer; grid of ~7 blocks per
+    // output tile set, between 2 and 16 blocks per CU
+    const int tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
+    int pix = 64, db = 1, target = 7 * tiles;
+    if (target < 512) target = 512;
+    if (target > 4096) target = 4096;
+    if (g_tune_wg_pix) pix = g_tune_wg_pix;
+    if (g_tune_wg_db) db = g_tune_wg_db;
+    if (g_tune_wg_blocks) target = g_tune_wg_blocks;
+    if (int e = launch_wgrad_f32(a, tn, tk, pix, db, target, st)) return e;
+  }
   HRSEG_LAUNCH_CHECK("wgrad");
   return 0;
 }
@@ -1779,3 +1193,4 @@ extern "C" int hrseg_tune(const char* key, int value) {
   hrseg_set_error("hrseg_tune: unknown key '%s'", key);
   return HRSEG_ERR_INVALID_ARG;
 }
+

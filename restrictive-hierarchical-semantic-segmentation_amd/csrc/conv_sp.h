@@ -951,6 +951,7 @@ struct WeightImageGroup {
   const float* w[MAXG];
   unsigned char* img[MAXG];
 };
+#ifdef HRSEG_TU_WS          // non-template kernels are defined in the one translation unit that launches them
 __global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g) {
   int gi = 0;
   while (gi + 1 < g.n && (int)blockIdx.x >= g.blk_end[gi]) ++gi;
@@ -960,6 +961,7 @@ __global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g
   else if (kind == 3) sp_weight_image_body<4, 4>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
   else sp_weight_image_body<3, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
 }
+#endif
 
 template <int NS, int TH, int WTN, int CS, int FLIP>
 __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end) {
@@ -1535,6 +1537,7 @@ struct Wgrad9Reduce {
   int nchunks[WG9_MAXG];
   long n4[WG9_MAXG];
 };
+#ifdef HRSEG_TU_WGRAD_SP
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(Wgrad9Reduce r) {
   // block = 32 consecutive float4 x 8 chunk groups (group j sums chunks j, j+8, ... in order); the eight partial
   // sums meet in LDS and are added in a fixed tree order: the same bits every run
@@ -1559,3 +1562,4 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(Wgrad9Reduce r) {
     __syncthreads();
   }
 }
+#endif
