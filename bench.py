@@ -47,6 +47,12 @@ CONV_ARITHMETIC = {
     "auto": "fp32-grade throughout: fp16x2 (2 fp16 pieces per fp32 operand, 3 products on v_mfma_f32_16x16x32_f16, "
             "fp32 accumulate) where it is the faster kernel family, exact-fp32 v_mfma_f32_16x16x4_f32 kernels on the "
             "small problems; all weight gradients fp16x2"}
+# the bench line's "dtype": the arithmetic type the convolution contractions compute in, spelled out
+DTYPE_LABEL = {"f32": "f32 (exact fp32 MFMA)",
+               "auto": "f32 (fp16x2 split on fp16 MFMA, 22-bit operands, fp32 accumulate; exact-fp32 MFMA on the small problems)",
+               "fp16x2": "f32 (fp16x2 split on fp16 MFMA, 22-bit operands, fp32 accumulate)",
+               "bf16x3": "f32 (bf16x3 split on bf16 MFMA, 24-bit operands, fp32 accumulate)",
+               "bf16x2": "bf16x2 split (16-bit operands, fp32 accumulate)", "bf16": "bf16 operands, fp32 accumulate"}
 CONV_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1, "fp16x2": 3, "auto": 3}
 TRAIN_GFLOP_PER_IMAGE = {          # BASELINE.md section 2 (conv+linear MACs x2, fwd+dgrad+wgrad = 3x fwd), 620x620
     ("hrnet", True): 1662.0, ("hrnet", False): 831.0, ("unet", True): 2168.0, ("unet", False): 1084.0}
@@ -73,6 +79,11 @@ def parse():
                     help="skip the extra measurement of the opt-in bf16-input convolutions (N=1)")
     ap.add_argument("--no-dedup-line", action="store_true",
                     help="skip the extra measurement of the opt-in de-duplicated level passes (N=1, hierarchical)")
+    ap.add_argument("--no-f32-line", action="store_true",
+                    help="skip the extra measurement with the exact-fp32 MFMA convolutions (N=1)")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="time ONLY the gradient exchange of a step (the bucketed all-reduce of the flat gradient buffer, "
+                         "as GradSync issues it) on N ranks: compute and exchange can then be read apart in a scaling run")
     return ap.parse_args()
 
 
@@ -232,25 +243,46 @@ def probe_secondary_kernels(device, batch, size, conv_dtype="auto"):
     ]
 
 
+def _csrc_digest():
+    """sha256 over the kernel sources: recorded counters are only quoted for the sources they were collected on"""
+    import hashlib
+    d = os.path.join(ROOT, "restrictive-hierarchical-semantic-segmentation_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_PROFILE = "r03"
+
+
 def pmc_value(kernel, what):
-    """Recorded rocprofv3 PMC results for `kernel` (counters cannot be collected from inside this process):
+    """RECORDED rocprofv3 PMC results for `kernel` (counters cannot be collected from inside this process):
     'traffic'   -- HBM bytes per launch: FETCH_SIZE (doubled, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
                    separate --pmc passes over full train steps (profiles/README.md)
-    'mfma_busy' -- SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES ... ) as recorded in the csv's mfma_busy column
-    -> (value, source) or (None, None)."""
+    'mfma_busy' -- SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) as recorded in the csv's mfma_busy column
+    -> (value, source) or (None, reason).  profiles/<PMC_PROFILE>_meta.json names the kernel-source digest the counters
+    were collected on (tools/collect_profiles.sh writes it); with other sources the recorded values are NOT quoted."""
     import csv
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    fname = {"traffic": "r02b_pmc_traffic_per_launch.csv", "mfma_busy": "r02b_pmc_mfma_busy.csv"}[what]
+    root = os.path.join(ROOT, "profiles")
+    fname = {"traffic": PMC_PROFILE + "_pmc_traffic_per_launch.csv", "mfma_busy": PMC_PROFILE + "_pmc_mfma_busy.csv"}[what]
     try:
+        meta = json.load(open(os.path.join(root, PMC_PROFILE + "_meta.json")))
+        if meta.get("csrc_digest") != _csrc_digest():
+            return None, "profiles/%s was recorded on other kernel sources (digest %s, now %s): not quoted" % (
+                fname, meta.get("csrc_digest"), _csrc_digest())
         for row in csv.DictReader(open(os.path.join(root, fname))):
             if row["kernel"].startswith(kernel):
+                tag = "RECORDED in profiles/%s on these kernel sources (commit %s)" % (fname, meta.get("commit", "?"))
                 if what == "traffic":
                     mb = float(row["FETCH_bytes_MB_corrected_x2"]) + float(row["WRITE_MB"])
-                    return round(mb * 2**20), "profiles/%s (rocprofv3 --pmc, all launches of full train steps)" % fname
-                return round(float(row["mfma_busy"]), 4), "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES-based, see README)" % fname
+                    return round(mb * 2**20), tag + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over full train steps"
+                return round(float(row["mfma_busy"]), 4), tag + ": SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)"
     except (OSError, KeyError, ValueError):
         pass
-    return None, None
+    return None, "no recorded counters under profiles/%s_*" % PMC_PROFILE
 
 
 def host_cores():
@@ -336,6 +368,58 @@ def self_launch(args):
     return proc.returncode if proc.returncode != 0 or lines else 1
 
 
+def comm_only(args, model, sync, rank, world, device):
+    """the gradient exchange of one step in isolation: the buckets GradSync issues during the last backward level
+    (same boundaries, same side stream, same backend), on a gradient buffer of the model's size, nothing else running.
+    One JSON line from rank 0: ms per exchange, algorithm bandwidth (bytes / time) and ring bus bandwidth
+    (2 (N-1)/N x that), so that a scaling run can tell compute from exchange (reference: train.py:509-510)."""
+    import torch.distributed as dist
+    from hrseg_amd.parallel import GradSync, bucket_offsets
+    flat = model.flatten_parameters(device)
+    if sync is None:
+        os.environ["HRSEG_FORCE_SYNC"] = "1"
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        sync = GradSync(model)
+    offs = bucket_offsets(flat, sync.marks)
+    marks = sorted(offs, key=lambda m: -offs[m])          # the order the reverse pass crosses them
+    flat.grad.normal_()
+
+    def exchange():
+        for m in marks:
+            sync(m)
+        sync("end")
+
+    for _ in range(max(1, args.warmup)):
+        exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        exchange()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank == 0:
+        nbytes = flat.numel * 4
+        ms = 1e3 * dt / args.steps
+        algbw = nbytes / (dt / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "gradient exchange per step (bucketed all-reduce of the flat fp32 gradient)", "value": round(ms, 3),
+            "unit": "ms", "higher_is_better": False, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "bytes": nbytes, "buckets": [[lo, hi] for lo, hi in sync.launched], "algbw_GBps": round(algbw, 1),
+            "busbw_GBps": round(algbw * 2 * (world - 1) / max(world, 1), 1) if world > 1 else None,
+            "backend": sync.backend + ":" + (dist.get_backend() if dist.is_initialized() else "-"),
+            "note": "exchange only, no compute beside it; in a train step it overlaps pass 0 of the backward"}), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,6 +444,12 @@ def main():
             sync = GradSync(model)
         opt.grad_scale = 1.0 / world
     hier = not args.flat
+    if args.comm_only:
+        comm_only(args, model, sync, rank, world, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     x_np, t_np = synth.synthetic_batch(tree, args.batch, args.size, seed=100 + rank, hierarchical=hier)
     x_host, t_host = torch.from_numpy(x_np).pin_memory(), torch.from_numpy(t_np).pin_memory()
     x, t = x_host.to(device), t_host.to(device)
@@ -442,7 +532,8 @@ def main():
             "train images/sec (%dx%d, %s%s)" % (args.size, args.size, "hier-" if hier else "flat-", args.model),
             "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL.get(conv_dtype, conv_dtype),
+            "data": "synthetic",
             "config": {"workload": "%s %s (%s), %dx%d, batch %d per GPU, train_epoch batch body (fwd L passes, prediction prep "
                                    "+ metrics, CE+Dice+consistency, bwd, grad all-reduce, AdamW, metric vectors, one D2H "
                                    "readback of loss+metrics)" % (
@@ -493,6 +584,24 @@ def main():
                 "dtype": "bf16 inputs, fp32 accumulate (convolutions only; BN, loss, optimizer fp32)",
                 "note": "explicit opt-in (model.conv_dtype='bf16'): results differ from the fp32 reference beyond 1e-3"}
             log("opt-in bf16 convs: %.1f ms/step" % (1e3 * tb / args.steps))
+        if world == 1 and graphed is None and not args.no_f32_line and hasattr(model, "conv_dtype") and conv_dtype != "f32":
+            # the same step with every contraction on the exact-fp32 matrix instruction (model.conv_dtype = "f32"): the
+            # figure to hold next to the headline, whose contractions run as fp16x2 splits
+            prev = model.conv_dtype
+            model.conv_dtype = "f32"
+            for _ in range(2):
+                step()
+            tf32, loss32 = timed(step, args.steps)
+            model.conv_dtype = prev
+            line["exact_f32_convs"] = {
+                "value": round(args.batch * args.steps / tf32, 3), "unit": "images/s", "ms_per_step": round(1e3 * tf32 / args.steps, 2),
+                "dtype": "f32 (exact fp32 MFMA, v_mfma_f32_16x16x4_f32)", "final_loss": loss32,
+                "note": "model.conv_dtype='f32': every convolution on the exact-fp32 MFMA kernels; never the headline value"}
+            if gf is not None and args.size == 620:
+                tfl = args.batch * args.steps / tf32 * gf / 1e3
+                line["exact_f32_convs"].update(achieved_tflops=round(tfl, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                                               frac=round(tfl / FP32_MFMA_PEAK_TFLOPS, 4))
+            log("exact-fp32 convs: %.1f ms/step" % (1e3 * tf32 / args.steps))
         if not args.no_probe:
             # the level passes run batched: every conv launch sees batch * L images
             n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1

@@ -9,8 +9,13 @@
  *
  * Conventions
  *   - plain pointers + sizes; every pointer is DEVICE memory owned by the
- *     caller (PyTorch's caching allocator); the library allocates nothing and
- *     keeps no state besides a thread-local error string.
+ *     caller (PyTorch's caching allocator); the library allocates nothing.
+ *   - process-wide state (all of it listed here): a thread-local error string;
+ *     the tuning overrides of hrseg_tune (plain ints, set them before launching
+ *     from several threads); the scratch buffer attached with hrseg_set_scratch
+ *     (ONE buffer per process, bound to the device that was current when it was
+ *     attached -- launches on another device do not use it -- whose region table
+ *     is mutex-protected); the launch counters of hrseg_launch_count.
  *   - activations are NHWC fp32, addressed as pixel*ld + channel ("ld" =
  *     floats per pixel row, >= C, multiple of 4) so a kernel can read or
  *     write a channel slice of a wider tensor (concat without a copy).
@@ -58,12 +63,17 @@ int hrseg_abi_version(void);
  *           at 16/6 of the fp32 matrix rate
  *   BF16X2  2 pieces, 3 products (operand error 2^-16)
  *   BF16    operands rounded to bf16, fp32 accumulation (BASELINE configs[4] arithmetic)
- *   AUTO    fp32-grade results from the faster family per problem: BF16X3 for forward / data-gradient
- *           problems of at least 8192 output pixels, F32 for small ones and for weight gradients
+ *   AUTO    fp32-grade results from the faster family per problem: FP16X2 for forward / data-gradient problems of
+ *           at least 8192 output pixels, for every 3x3 stride-1 problem the wave-specialised kernels take (>= 96
+ *           tiles) and for every weight gradient; F32 for the remaining small problems
  *   FP16X2  each operand scaled by a power of two and split into 2 fp16 pieces (22 significand bits), the 3
  *           largest piece products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: operand error 2^-22 at
  *           half the matrix work of BF16X3.  Weights are scaled by 2^8, gradient operands by 2^14 / |max|
- *           (`grad_absmax`, written by hrseg_bn_bwd_group), activations are clamped to +-65504.            */
+ *           (`grad_absmax`, written by hrseg_bn_bwd_group); activations are NOT scaled and NOT clamped:
+ *           |x| <= 65504 is exact to 22 bits, up to ~1.3e5 the low piece absorbs the excess, beyond that the
+ *           result is Inf / NaN (loud, never a silently saturated value); NaN / Inf inputs propagate.  A caller
+ *           that cannot bound its activations checks them with hrseg_absmax and passes F32 (ops.py does so in
+ *           deterministic mode).                                                                             */
 enum hrseg_conv_precision { HRSEG_CONV_F32 = 0, HRSEG_CONV_BF16X3 = 1, HRSEG_CONV_BF16X2 = 2, HRSEG_CONV_BF16 = 3, HRSEG_CONV_AUTO = 4,
                             HRSEG_CONV_FP16X2 = 5 };
 typedef struct {
@@ -114,19 +124,25 @@ size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape_t* shapes)
 int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
                               const hrseg_conv_shape_t* shapes, void* workspace, size_t workspace_bytes,
                               hrseg_stream_t stream);
+/* launches issued so far by kernel family ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32",
+ * "f32_group", "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9"; NULL = all); reset != 0 zeroes what it returns.
+ * The parity tests use it to prove which kernels a case ran. */
+long hrseg_launch_count(const char* family, int reset);
 /* tile-plan overrides and A/B switches for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
  * wgrad_group_min, wgrad_group_max (fp32 kernels); sp_wtm, sp_wtn, sp_ksplit, sp_patch, sp_persist (split-precision
  * kernels); sp_ws (0: never use the wave-specialised 3x3 kernels), sp_ws_n48 (0: 48-channel tilings stay on the
  * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_img (0: block-synchronous kernels
  * split their weights on the fly); wgrad9, wgrad9_blocks (nine-tap weight gradient); deterministic (1: single-adder
- * reductions everywhere) -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
+ * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
+ * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
 int hrseg_tune(const char* key, int value);
 /* Scratch memory for the convolution launches (device, 256-byte aligned, at least 1 MiB; 256 MiB covers every layer
  * of the reference's models): the wave-specialised fp16x2 kernels of the wide 3x3 stride-1 layers read their weights
  * from a pre-split image (4 bytes per weight) that a small kernel writes there right before each launch, on the same
- * stream (up to eight streams get an eighth of the buffer each; a layer whose image does not fit its region, or a
- * ninth stream, takes the block-synchronous kernels).  The buffer stays the caller's and must outlive the launches; (NULL, 0) detaches it.
+ * stream (up to eight streams get an eighth of the buffer each, as a ring; the images of one grouped launch are reserved
+ * together, so the ring never wraps inside a group; a group whose images do not fit a region, a ninth stream, or a launch
+ * on another device than the one current at attach time takes the block-synchronous kernels).  The buffer stays the caller's and must outlive the launches; (NULL, 0) detaches it.
  * Without it those layers run the block-synchronous kernels: same results, slower. */
 int hrseg_set_scratch(void* ptr, size_t bytes);
 /* wt[ci][t][co] = w[co][t][ci] */
@@ -185,8 +201,17 @@ typedef struct {
                                                         the running averages / num_batches_tracked
                                                         (0 or 1 = once; L = de-duplicated level
                                                         passes, see Models/models.py)               */
+  int stat_ranks;                                    /* cross-rank statistics (opt-in synchronised BN): the
+                                                        partial sums were all-reduced over this many ranks of
+                                                        equal shards between the statistics and the finalize
+                                                        phase, so the statistics cover stat_ranks*npix pixels
+                                                        (0 or 1 = this rank only, the reference's behaviour)  */
 } hrseg_bn_fwd_t;
 int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
+/* the same in phases (bit 0 statistics, bit 1 finalize / eval coefficients, bit 2 apply; 7 = all): a caller that
+ * synchronises BatchNorm statistics across ranks runs phase 1, all-reduces `partial`, then runs phases 2|4 with
+ * stat_ranks set (the reference's SyncBatchNorm would do this WITH a process group; it never has one) */
+int hrseg_bn_fwd_group_phases(int n, const hrseg_bn_fwd_t* problems, int training, int phases, hrseg_stream_t stream);
 typedef struct {
   const float* dz; int lddz; const float* z; int ldz; int relu;   /* relu with z == NULL: the forward had
                                                         no residual, the mask is recomputed from y    */
@@ -203,8 +228,15 @@ typedef struct {
                                                         level passes), each normalised on its own: the
                                                         batch means of the backward are per segment;
                                                         must divide nchunks and npix (0 or 1 = plain)  */
+  int sum_ranks;                                     /* cross-rank statistics: the partial sums were all-reduced
+                                                        over this many ranks between the reduce and the finalize
+                                                        phase; the finalize divides them by it, so that the batch
+                                                        means are global and dgamma / dbeta receive this rank's
+                                                        share (0 or 1 = this rank only)                      */
 } hrseg_bn_bwd_t;
 int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* problems, int eval_mode, hrseg_stream_t stream);
+/* phases: bit 0 reduce, bit 1 finalize, bit 2 apply (7 = all), see hrseg_bn_fwd_group_phases */
+int hrseg_bn_bwd_group_phases(int n, const hrseg_bn_bwd_t* problems, int eval_mode, int phases, hrseg_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling / resampling / glue
  * nn.MaxPool2d(2) (models.py:140); bilinear align_corners=True resize
@@ -223,6 +255,9 @@ int hrseg_bilinear_fwd(const float* in, int ldin, int B, int Hi, int Wi, int C, 
 int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, int Wi, int C, float* din,
                        int lddin, int Hout, int Wout, int Hr, int Wr, int py, int px,
                        int align_corners, int accumulate, hrseg_stream_t stream);
+/* max|x| of an NHWC tensor: slot (block % 64) of the 64-float DEVICE array out64 (zeroed by the caller) is raised to
+ * the maximum of its blocks; NaN counts as +Inf.  Range check in front of FP16X2 convolutions (see above). */
+int hrseg_absmax(const float* x, int ldx, long npix, int C, float* out64, hrseg_stream_t stream);
 /* out = relu?(a + b) ; strided channel copy ; masked relu backward */
 int hrseg_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int relu,
               long npix, int C, hrseg_stream_t stream);
@@ -303,6 +338,16 @@ int hrseg_consistency(const float* p, const float* pprev, double* out, int B, in
 int hrseg_consistency_bwd(const float* p, const float* pprev, const float* g, float scale, float* dp,
                           float* dpprev, int B, int C, int Cprev, long hw, int ngroups,
                           const int* group_parent, const int* group_size, hrseg_stream_t stream);
+/* Grouped conditional KL, the opt-in stabiliser the reference keeps commented out (Metrics/losses.py:180-210): per parent
+ * group of the level Q = softmax_c(z_c + log(Pprev[parent] + 1e-6)).clamp_min(1e-8) over the group's children;
+ * out[g] (double, +=) = sum over b, pixels and the group's children of Q * (log Q + log size_g), i.e. KL(Q || Uniform)
+ * before the mean.  hrseg_group_kl_bwd writes dz [B,C,hw] = g[0] * scale * d/dz sum_g out[g] / size_g (Pprev gets no
+ * gradient: the log-bias is constant inside a group).  Default off in the train loop. */
+int hrseg_group_kl(const float* z, const float* pprev, double* out, int B, int C, int Cprev, long hw, int ngroups,
+                   const int* group_parent, const int* group_size, hrseg_stream_t stream);
+int hrseg_group_kl_bwd(const float* z, const float* pprev, const float* g, float scale, float* dz, int B, int C,
+                       int Cprev, long hw, int ngroups, const int* group_parent, const int* group_size,
+                       hrseg_stream_t stream);
 /* argmax one-hot of z masked by t!=-1, plus confusion matrix counts
  * cm[(C+child)*(C+child)] (int64, +=) of (target label, predicted label) with
  * the synthetic background class 0 for child levels. mask_pred=1 is the train

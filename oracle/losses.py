@@ -94,3 +94,25 @@ def get_loss(output_logits, targets, level_weights, probs_per_level=None, levels
         cons = hierarchical_consistency_loss(probs_per_level, levels, parent_of)
         loss = loss + cons
     return loss, parts, cons
+
+
+def grouped_conditional_kl(z_children_all, probs_prev_level, groups, levels_prev):
+    """restates the commented-out stabiliser of the reference (Metrics/losses.py:180-210) with stock torch ops:
+    per parent group KL(softmax(z_g + log(P_p + 1e-6)).clamp_min(1e-8) || Uniform).mean(), averaged over groups"""
+    if z_children_all is None or probs_prev_level is None or groups is None:
+        return z_children_all.sum() * 0
+    kl, gcount, start = 0.0, 0, 0
+    for pname, chnames in groups:
+        g = len(chnames)
+        if g == 0:
+            continue
+        z_g = z_children_all[:, start:start + g]
+        p_p = probs_prev_level[:, levels_prev.index(pname):levels_prev.index(pname) + 1]
+        q = torch.softmax(z_g + torch.log(p_p + 1e-6), dim=1).clamp_min(1e-8)
+        u = torch.full_like(q, 1.0 / g)
+        kl = kl + (q * (q.log() - u.log())).mean()
+        gcount += 1
+        start += g
+    if gcount == 0:
+        return z_children_all.sum() * 0
+    return kl / gcount

@@ -46,13 +46,13 @@ class FiLM(nn.Module):
 def compose_levels(logits_fn, levels, groups_per_level, n_levels):
     """Level loop shared by UNet and HRNet (models.py:263-306, :760-802).
 
-    logits_fn(L, probs_prev) -> z_L [B,C_L,H,W]."""
+    logits_fn(L, probs_prev, logits_prev) -> z_L [B,C_L,H,W]."""
     probs, logits = [], []
-    z0 = logits_fn(0, None)
+    z0 = logits_fn(0, None, None)
     probs.append(torch.sigmoid(z0))
     logits.append(z0)
     for L in range(1, n_levels):
-        z = logits_fn(L, probs[L - 1])
+        z = logits_fn(L, probs[L - 1], logits[L - 1])
         groups = groups_per_level[L - 1]
         logits.append(z)
         if not groups:
@@ -123,9 +123,13 @@ class _Out(nn.Module):
 
 
 class UNet(nn.Module):
-    def __init__(self, size=620, n_channels=1, hierarchy={}, model_type=0):
+    def __init__(self, size=620, n_channels=1, hierarchy={}, model_type=0, concat_prev_logits=False):
+        """concat_prev_logits (opt-in extension, SURVEY 8(f4) / north_star wording; the reference re-runs on the image
+        only, models.py:267,277): level L >= 1 re-encodes cat(image, logits_{L-1}) -- its first convolution is
+        `cond_stems[L-1]` (n_channels + C_{L-1} inputs), every other layer is shared with level 0."""
         super().__init__()
         self.model_type, self.hierarchy = model_type, hierarchy
+        self.concat_prev_logits = bool(concat_prev_logits) and model_type != 0
         self.inc0 = _In(n_channels, 64)
         self.down1, self.down2 = _Down(64, 128), _Down(128, 256)
         self.down3, self.down4 = _Down(256, 512), _Down(512, 512)
@@ -143,9 +147,17 @@ class UNet(nn.Module):
                 self.heads.append(_Out(64, n if n > 0 else 1))
             self.films = nn.ModuleList([FiLM(64, len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
+            if self.concat_prev_logits:
+                self.cond_stems = nn.ModuleList([nn.Conv2d(n_channels + self.heads[L - 1].conv.out_channels, 64, 3, padding=1)
+                                                 for L in range(1, len(self.levels))])
 
-    def _run_unet(self, x):
-        x1 = self.inc0(x)
+    def _run_unet(self, x, first=None):
+        if first is None:
+            x1 = self.inc0(x)
+        else:                                   # the level's own first convolution, then the shared rest of inc0
+            x1 = first(x)
+            for mod in list(self.inc0.conv.conv)[1:]:
+                x1 = mod(x1)
         x2 = self.down1(x1)
         x3 = self.down2(x2)
         x4 = self.down3(x3)
@@ -159,8 +171,11 @@ class UNet(nn.Module):
         if self.model_type == 0 or type == 0:
             return [], self.out_flat(self._run_unet(x))
 
-        def logits_fn(L, prev):
-            d = self._run_unet(x)
+        def logits_fn(L, prev, zprev):
+            if L > 0 and self.concat_prev_logits:
+                d = self._run_unet(torch.cat([x, zprev], dim=1), self.cond_stems[L - 1])
+            else:
+                d = self._run_unet(x)
             if L > 0:
                 d = self.films[L - 1](d, prev)
             return self.heads[L](d)
@@ -283,8 +298,9 @@ class HighResolutionModule(nn.Module):
 
 
 class HighResolutionNet(nn.Module):
-    def __init__(self, config, hierarchy={}, model_type=0, **kwargs):
+    def __init__(self, config, hierarchy={}, model_type=0, concat_prev_logits=False, **kwargs):
         super().__init__()
+        self.concat_prev_logits = bool(concat_prev_logits) and model_type != 0     # see UNet
         extra = config.MODEL.EXTRA
         self.align_corners = config.MODEL.ALIGN_CORNERS
         self.model_type, self.hierarchy = model_type, hierarchy
@@ -321,6 +337,9 @@ class HighResolutionNet(nn.Module):
                 self.classifiers.append(nn.Conv2d(last, n if n > 0 else 1, k, 1, pad))
             self.films = nn.ModuleList([FiLM(last, len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
+            if self.concat_prev_logits:
+                self.cond_stems = nn.ModuleList([_c3(3 + self.classifiers[L - 1].out_channels, 64, 2)
+                                                 for L in range(1, len(self.levels))])
 
     @staticmethod
     def _transition(pre, cur):
@@ -349,8 +368,14 @@ class HighResolutionNet(nn.Module):
             num_in = mods[-1].num_inchannels
         return nn.Sequential(*mods), num_in
 
-    def _forward_backbone(self, x):
-        x = self.layer1(self.stem(x))
+    def _forward_backbone(self, x, first=None):
+        if first is None:
+            x = self.stem(x)
+        else:
+            x = first(x)
+            for mod in list(self.stem)[1:]:
+                x = mod(x)
+        x = self.layer1(x)
         ys = [x]
         for t_idx, cfg in zip((1, 2, 3), self.stage_cfgs):
             trans = getattr(self, f"transition{t_idx}")
@@ -375,8 +400,11 @@ class HighResolutionNet(nn.Module):
         if self.model_type == 0:
             return [], up(self.classifier(self._forward_backbone(x)))
 
-        def logits_fn(L, prev):
-            f = self._forward_backbone(x)
+        def logits_fn(L, prev, zprev):
+            if L > 0 and self.concat_prev_logits:
+                f = self._forward_backbone(torch.cat([x, zprev], dim=1), self.cond_stems[L - 1])
+            else:
+                f = self._forward_backbone(x)
             if L > 0:
                 f = self.films[L - 1](f, prev)
             return up(self.classifiers[L](f))

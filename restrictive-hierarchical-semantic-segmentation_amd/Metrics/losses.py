@@ -58,6 +58,28 @@ def fused_ce_dice(logits, targets, class_weight):
     return _FusedLoss.apply(logits, targets, _weights(class_weight, logits.device))
 
 
+def global_batch_dice(res, group=None):
+    """Dice term of one level under data parallelism.  The reference computes Dice on the batch gathered on one GPU:
+    mean over the items whose Dice is not 0/0 (losses.py:64-66), so the divisor is the GLOBAL number of valid items.
+    A rank-local mean divides by the rank's own count, which differs from rank to rank as soon as one shard holds a
+    sample with no valid pixel at this level.  With n_r = this rank's count and n = sum over ranks (ONE all-reduce of
+    one float per level, stream-ordered, no host sync) the rank's term becomes
+
+        dice_r * n_r * world / n      (0 when n == 0)
+
+    whose average over the ranks -- what GradSync's summed gradient times AdamW's 1/world evaluates -- is
+    sum_b dice_b / n: exactly the gathered-batch Dice and its gradient.  `res` = fused_ce_dice(...)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return res[1]
+    n_local = res[2].detach()
+    n = n_local.clone().reshape(1)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    world = float(dist.get_world_size(group))
+    scale = torch.where(n > 0, n_local.reshape(1) * world / n.clamp(min=1.0), torch.zeros_like(n))
+    return res[1] * scale.reshape(())
+
+
 def _as_logits(outs, logits_input, log_domain):
     """The kernels take logits.  Already-normalised inputs are mapped back:
     log-probabilities are their own logits; probabilities go through log()."""
@@ -140,3 +162,38 @@ def hierarchical_consistency_loss(probs_per_level, levels, parent_of, reduction=
     if count == 0:
         return probs_per_level[0].sum() * 0
     return total / count
+
+
+class _GroupKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, pprev, gp, gs):
+        z, pprev = z.contiguous(), pprev.contiguous()
+        sums = ops.group_kl_sums(z, pprev, gp, gs)
+        n = z.shape[0] * z.shape[2] * z.shape[3]
+        sizes = torch.tensor([float(v) for v in gs], dtype=torch.float64, device=z.device)
+        ctx.save_for_backward(z, pprev)
+        ctx.meta = (gp, gs, 1.0 / (n * len(gs)))
+        return ((sums / sizes).sum() / (n * len(gs))).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        z, pprev = ctx.saved_tensors
+        gp, gs, scale = ctx.meta
+        return ops.group_kl_bwd(z, pprev, g.reshape(1).float().contiguous(), scale, gp, gs), None, None, None
+
+
+def grouped_conditional_kl(z_children_all, probs_prev_level, groups, levels_prev):
+    """The optional stabiliser the reference ships commented out (Metrics/losses.py:180-210), same signature: per parent
+    group KL(Q_{c|p} || Uniform) with Q = softmax(z_g + log(P_p + 1e-6)).clamp_min(1e-8), `.mean()` per group, averaged
+    over the groups that have children.  One fused HIP pass forward (hrseg_group_kl), one for the gradient w.r.t. the
+    logits (hrseg_group_kl_bwd; the parent probabilities get none: the log-bias is constant inside a group).
+    groups: [(parent_name, [child names])] of this level; levels_prev: parent names in channel order.  Opt-in:
+    train.get_loss adds `lambda_kl` times it per level only when asked to."""
+    if z_children_all is None or probs_prev_level is None or groups is None:
+        return z_children_all.sum() * 0
+    live = [(levels_prev.index(p), len(ch)) for p, ch in groups if len(ch) > 0]
+    if not live:
+        return z_children_all.sum() * 0
+    if sum(g for _, g in live) != z_children_all.shape[1]:
+        raise ValueError("group sizes do not add up to the level's channels")
+    return _GroupKL.apply(z_children_all, probs_prev_level, [p for p, _ in live], [g for _, g in live])

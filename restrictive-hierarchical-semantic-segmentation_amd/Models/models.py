@@ -115,12 +115,15 @@ class _Run:
         dp_full = [dprobs[L] if hierarchical and dprobs[L] is not None else None for L in range(n)]
         dp_own = [False] * n            # True once the buffer is ours to accumulate into
         dp_bcast = [None] * n
+        dz_input = [None] * n           # logit-concatenated re-encoding: d loss / d logits_L through level L+1's input
         for L in reversed(range(n)):
             lv = self.levels[L]
             z = lv["z"]
             dz, own = dlogits[L], False
             if dz is not None:
                 dz = dz.contiguous()
+            if dz_input[L] is not None:
+                dz, own = (dz_input[L], True) if dz is None else (ops.accumulate_flat(ops.clone(dz), dz_input[L]), True)
             if hierarchical:
                 for dp in (dp_full[L], dp_bcast[L]):
                     if dp is None:
@@ -151,6 +154,9 @@ class _Run:
                 continue                 # the heads' feature gradients accumulate; one reverse pass below
             hook = m._grad_hook if (L == 0) else None
             lv["rec"].backward(hook)
+            xin = lv.get("xin")
+            if xin is not None and xin.grad is not None and L > 0:
+                dz_input[L - 1] = ops.nhwc_slice_to_nchw(xin.grad, xin.grad.shape[3] - self.logits[L - 1].shape[1])
             lv.clear()
         if self.shared_tape and n > 0:
             lv0 = self.levels[0]
@@ -196,6 +202,11 @@ class _EngineModel(nn.Module):
         self.conv_dtype = os.environ.get("HRSEG_CONV_DTYPE", DEFAULT_CONV_DTYPE)
         env = os.environ.get("HRSEG_SEQUENTIAL_PASSES")
         self.sequential_passes = (env == "1") if env is not None else not self.batch_passes_by_default
+        # opt-in extensions, all default off: `concat_prev_logits` is a constructor argument (it adds the
+        # cond_stems parameters); `sync_bn` = BatchNorm statistics over all ranks (what the reference's SyncBatchNorm would
+        # do WITH a process group, bn_helper.py:4-11 -- the reference itself never synchronises)
+        self.sync_bn = os.environ.get("HRSEG_SYNC_BN", "0") == "1"
+        self.sync_bn_group = None
 
     # -- parameters -------------------------------------------------------------------------
     def flatten_parameters(self, device=None):
@@ -232,7 +243,7 @@ class _EngineModel(nn.Module):
         x_nhwc = Act(ops.nchw_to_nhwc(x.contiguous().float()), needs_grad=False)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
-            rec = Recorder(self.training, record, self._flat, prec=prec)
+            rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync())
             feats = self._backbone(rec, x_nhwc)
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
@@ -247,6 +258,10 @@ class _EngineModel(nn.Module):
         # their feature gradients are summed and ONE reverse pass runs -- the same result up to fp32
         # summation order at 1/L of the backbone work (executed FLOPs change; bench.py reports it apart).
         n_levels = len(self.levels)
+        concat = bool(getattr(self, "concat_prev_logits", False))
+        if concat and self.dedup_passes:
+            raise RuntimeError("hrseg_amd: dedup_passes needs identical level passes; concat_prev_logits makes every level "
+                               "re-encode its own input")
         dedup = bool(self.dedup_passes) and self.training and n_levels > 1
         # Default in training: the L passes run BATCHED -- the image batch is stacked L times and every layer
         # is one launch for all passes.  Each pass is still computed in full (same FLOPs as L sequential
@@ -254,25 +269,33 @@ class _EngineModel(nn.Module):
         # variance uses one pass's pixel count, running statistics take L updates, the backward normalises
         # each pass on its own); it halves the launch count and doubles the work per launch.
         # `sequential_passes` (HRSEG_SEQUENTIAL_PASSES=1) runs them one after the other as the reference does.
-        batched = (self.training and n_levels > 1 and not dedup and not self.sequential_passes
+        batched = (self.training and n_levels > 1 and not dedup and not self.sequential_passes and not concat
                    # 32-bit pixel indices in the kernels: larger stacks run the passes sequentially
                    and n_levels * x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31))
         run.shared_tape = (dedup or batched) and record
         shared, shared_rec = None, None
         Bn = x.shape[0]
         for L in range(n_levels):
+            xin = None
             if batched:
                 if shared is None:
-                    rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels, prec=prec)
+                    rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels, prec=prec,
+                                   sync=self._bn_sync())
                     xx = Act(x_nhwc.data.repeat(n_levels, 1, 1, 1), needs_grad=False)
                     shared, shared_rec = self._backbone(rec, xx), rec
                     run.batched_feats = shared
                 feats, rec = Act(shared.data[L * Bn:(L + 1) * Bn]), shared_rec
                 feats.slot = L               # its gradient is rows [L*B, (L+1)*B) of the stacked feature gradient
             elif shared is None:
-                rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1, prec=prec)
-                feats = self._backbone(rec, x_nhwc)
-                if dedup or (not self.training and not record):
+                rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1, prec=prec,
+                               sync=self._bn_sync())
+                if concat and L > 0:
+                    # level L re-encodes cat(image, logits_{L-1}) through its own first convolution (cond_stems[L-1])
+                    xin = Act(ops.concat_image_logits(x, run.logits[L - 1]), needs_grad=record)
+                    feats = self._backbone(rec, xin, first=self.cond_stems[L - 1])
+                else:
+                    feats = self._backbone(rec, x_nhwc)
+                if (dedup or (not self.training and not record)) and not concat:
                     shared, shared_rec = feats, rec
             else:
                 feats, rec = shared, shared_rec
@@ -290,11 +313,19 @@ class _EngineModel(nn.Module):
                     gs = [len(ch) for _, ch in g]
                     groups = (gp, gs)
                     p = ops.compose_fwd(z, run.probs[L - 1], gp, gs)
-            lv.update(rec=rec, groups=groups, stacked=run.batched_feats if batched else None)
+            lv.update(rec=rec, groups=groups, stacked=run.batched_feats if batched else None,
+                      xin=xin)
             run.levels.append(lv)
             run.probs.append(p)
             run.logits.append(z)
         return run
+
+    def _bn_sync(self):
+        """process group for cross-rank BatchNorm statistics, or None (the default: statistics stay per rank)"""
+        import torch.distributed as dist
+        if not self.sync_bn or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.sync_bn_group) == 1:
+            return None
+        return self.sync_bn_group if self.sync_bn_group is not None else dist.group.WORLD
 
     def _head_forward(self, rec, feats, head, film, p_prev, size):
         """FiLM (folded) + 1x1 head (+ bilinear resize for HRNet) -> logits NCHW."""
@@ -351,8 +382,8 @@ class double_conv(nn.Module):
         self.conv = nn.Sequential(Conv2d(in_ch, out_ch, 3, padding=1), BatchNorm2d(out_ch), nn.ReLU(inplace=True),
                                   Conv2d(out_ch, out_ch, 3, padding=1), BatchNorm2d(out_ch), nn.ReLU(inplace=True))
 
-    def run(self, rec, x):
-        x = rec.conv_bn(x, self.conv[0], self.conv[1], relu=True)
+    def run(self, rec, x, first=None):
+        x = rec.conv_bn(x, first if first is not None else self.conv[0], self.conv[1], relu=True)
         return rec.conv_bn(x, self.conv[3], self.conv[4], relu=True)
 
 
@@ -361,8 +392,8 @@ class inconv(nn.Module):
         super().__init__()
         self.conv = double_conv(in_ch, out_ch)
 
-    def run(self, rec, x):
-        return self.conv.run(rec, x)
+    def run(self, rec, x, first=None):
+        return self.conv.run(rec, x, first)
 
 
 class down(nn.Module):
@@ -396,10 +427,15 @@ class UNet(_EngineModel):
     """Flat (type==0): returns [], logits.  Hierarchical (type==1): level loop with FiLM."""
     batch_passes_by_default = False     # measured: 84.8 ms batched vs 83.2 ms sequential (hier, 620x620, B=4)
 
-    def __init__(self, size=620, n_channels=1, hierarchy={}, model_type=0):
+    def __init__(self, size=620, n_channels=1, hierarchy={}, model_type=0, concat_prev_logits=False):
+        """concat_prev_logits (opt-in extension, SURVEY 8(f4); north_star: "backbone re-run with logit-concatenated input";
+        the reference re-runs on the image only, models.py:267,277): level L >= 1 re-encodes cat(image, logits_{L-1})
+        through its own first convolution cond_stems[L-1]; every other layer is shared.  The level passes are then no
+        longer identical: they run one after the other, and dedup_passes is refused."""
         super().__init__()
         self.model_type = model_type
         self.hierarchy = hierarchy
+        self.concat_prev_logits = bool(concat_prev_logits) and model_type != 0
         self.inc0 = inconv(n_channels, 64)
         self.down1, self.down2 = down(64, 128), down(128, 256)
         self.down3, self.down4 = down(256, 512), down(512, 512)
@@ -417,6 +453,9 @@ class UNet(_EngineModel):
                 self.heads.append(outconv(64, n if n > 0 else 1))
             self.films = nn.ModuleList([FiLM(feat_ch=64, cond_ch=len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
+            if self.concat_prev_logits:
+                self.cond_stems = nn.ModuleList([Conv2d(n_channels + self.heads[L - 1].conv.out_channels, 64, 3, padding=1)
+                                                 for L in range(1, len(self.levels))])
         self._init_engine()
 
     def _flat_head(self):
@@ -425,8 +464,8 @@ class UNet(_EngineModel):
     def _level_head(self, L):
         return self.heads[L].conv
 
-    def _backbone(self, rec, x):
-        x1 = self.inc0.run(rec, x)
+    def _backbone(self, rec, x, first=None):
+        x1 = self.inc0.run(rec, x, first)
         x2 = self.down1.run(rec, x1)
         rec.mark("down2")            # gradient all-reduce bucket boundaries (parallel.py)
         x3 = self.down2.run(rec, x2)
@@ -630,11 +669,12 @@ class HighResolutionModule(nn.Module):
 class HighResolutionNet(_EngineModel):
     """Hierarchy-aware HRNet (flat: [], logits; hierarchical: probs, logits per level)."""
 
-    def __init__(self, config, hierarchy={}, model_type=0, **kwargs):
+    def __init__(self, config, hierarchy={}, model_type=0, concat_prev_logits=False, **kwargs):
         super().__init__()
         extra = config.MODEL.EXTRA
         self.align_corners = bool(config.MODEL.ALIGN_CORNERS)
         self.model_type = model_type
+        self.concat_prev_logits = bool(concat_prev_logits) and model_type != 0      # see UNet
         self.hierarchy = hierarchy
         self.relu = nn.ReLU(inplace=True)
         self.stem = nn.Sequential(Conv2d(3, 64, kernel_size=3, stride=2, padding=1, bias=False), _bn(64),
@@ -671,6 +711,9 @@ class HighResolutionNet(_EngineModel):
                 self.classifiers.append(Conv2d(last, n if n > 0 else 1, kernel_size=1))
             self.films = nn.ModuleList([FiLM(feat_ch=last, cond_ch=len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
+            if self.concat_prev_logits:
+                self.cond_stems = nn.ModuleList([Conv2d(3 + self.classifiers[L - 1].out_channels, 64, kernel_size=3, stride=2,
+                                                        padding=1, bias=False) for L in range(1, len(self.levels))])
         self._init_engine()
 
     _make_layer = staticmethod(_make_layer)
@@ -710,10 +753,10 @@ class HighResolutionNet(_EngineModel):
     def _level_head(self, L):
         return self.classifiers[L]
 
-    def _backbone(self, rec, x):
+    def _backbone(self, rec, x, first=None):
         # rec.mark(name): "every parameter registered at or after module `name` is final once the
         # reverse pass gets back here" (gradient all-reduce buckets, parallel.py)
-        x = rec.conv_bn(x, self.stem[0], self.stem[1], relu=True)
+        x = rec.conv_bn(x, first if first is not None else self.stem[0], self.stem[1], relu=True)
         x = rec.conv_bn(x, self.stem[3], self.stem[4], relu=True)
         rec.mark("layer1")
         x = _run_seq(rec, self.layer1, x)

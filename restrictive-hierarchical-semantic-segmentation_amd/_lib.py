@@ -44,14 +44,14 @@ class BnFwd(C.Structure):
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
                 ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
-                ("stat_div", _i), ("stat_updates", _i)]
+                ("stat_div", _i), ("stat_updates", _i), ("stat_ranks", _i)]
 
 
 class BnBwd(C.Structure):
     """hrseg_bn_bwd_t"""
     _fields_ = [("dz", _p), ("lddz", _i), ("z", _p), ("ldz", _i), ("relu", _i), ("y", _p), ("ldy", _i), ("coef", _p),
                 ("dgamma", _p), ("dbeta", _p), ("dy", _p), ("lddy", _i), ("dres", _p), ("lddres", _i),
-                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("dy_absmax", _p), ("nseg", _i)]
+                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("dy_absmax", _p), ("nseg", _i), ("sum_ranks", _i)]
 
 
 # name -> argtypes, exactly the prototypes of include/hrseg.h
@@ -73,10 +73,13 @@ PROTOTYPES = {
     "hrseg_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p],
     "hrseg_bn_fwd_group": [_i, C.POINTER(BnFwd), _i, _p],
     "hrseg_bn_bwd_group": [_i, C.POINTER(BnBwd), _i, _p],
+    "hrseg_bn_fwd_group_phases": [_i, C.POINTER(BnFwd), _i, _i, _p],
+    "hrseg_bn_bwd_group_phases": [_i, C.POINTER(BnBwd), _i, _i, _p],
     "hrseg_maxpool2_fwd": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "hrseg_maxpool2_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_bilinear_fwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_bilinear_bwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hrseg_absmax": [_p, _i, _l, _i, _p, _p],
     "hrseg_add": [_p, _i, _p, _i, _p, _i, _i, _l, _i, _p],
     "hrseg_copy": [_p, _i, _p, _i, _i, _l, _i, _p],
     "hrseg_relu_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _p],
@@ -98,6 +101,8 @@ PROTOTYPES = {
     "hrseg_loss_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _p],
     "hrseg_consistency": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
     "hrseg_consistency_bwd": [_p, _p, _p, _f, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_group_kl": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
+    "hrseg_group_kl_bwd": [_p, _p, _p, _f, _p, _i, _i, _i, _l, _i, _p, _p, _p],
     "hrseg_predict_metrics": [_p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     "hrseg_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     "hrseg_adamw_dev": [_p, _p, _p, _p, _l, _p, _p, _p],
@@ -149,13 +154,29 @@ def ensure_scratch(device):
 
 _lib.hrseg_tune.restype = _i
 _lib.hrseg_tune.argtypes = [C.c_char_p, _i]
+_lib.hrseg_launch_count.restype = C.c_long
+_lib.hrseg_launch_count.argtypes = [C.c_char_p, _i]
+
+_deterministic = False
+
+
+def launch_count(family=None, reset=False) -> int:
+    """convolution launches issued so far by kernel family (hrseg_launch_count; None = all families)"""
+    return int(_lib.hrseg_launch_count(None if family is None else family.encode(), int(reset)))
+
+
+def deterministic() -> bool:
+    return _deterministic
 
 
 def tune(**kv):
     """tile-plan overrides of the library (hrseg_tune; 0 = automatic), e.g. tune(igemm_wtm=2, igemm_kc=1)"""
+    global _deterministic
     for k, v in kv.items():
         if _lib.hrseg_tune(k.encode(), int(v)) != 0:
             raise RuntimeError(f"hrseg_tune({k}) failed: {last_error()}")
+        if k == "deterministic":
+            _deterministic = bool(v)
 
 
 def set_conv_tune(wtm=0, kc=0, db=0, ksplit=0):
@@ -178,7 +199,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 6     # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 7     # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

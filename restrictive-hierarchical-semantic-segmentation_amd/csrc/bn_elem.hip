@@ -497,6 +497,30 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   }
 }
 
+// max|x| of an NHWC tensor into a 64-slot array (slot = block % 64, as hrseg_bn_bwd_t.dy_absmax); NaN counts as +Inf so
+// that a non-finite tensor is never reported as in range.  `out` must be zeroed by the caller (hrseg_fill).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int ldx, long npix, int C,
+                                                     float* __restrict__ out) {
+  const Lanes L = make_lanes(C);
+  float amax = 0.f;
+  if (L.active) {
+    FOR_PIXELS(pix, L, npix) {
+      const f32x4 v = ld4(x + pix * ldx + 4 * L.cq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, (v[j] != v[j]) ? __builtin_inff() : fabsf(v[j]));
+    }
+  }
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out) + (blockIdx.x & 63), __float_as_uint(m));
+  }
+}
+
 // NCHW <-> NHWC for narrow tensors (image: C=3, logits: C<=16): thread per pixel
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int ldout, int B, int C,
                                     long hw) {
@@ -684,8 +708,9 @@ __device__ __forceinline__ void bn_finalize_channel(const hrseg_bn_fwd_t& p, int
   // stat_updates > 1: the same batch statistics enter the running averages that many times (the level
   // passes of the hierarchical models run as one) -- sequential updates, bit for bit
   const int reps = p.stat_updates > 1 ? p.stat_updates : 1;
-  const double mean = s / (double)p.npix;
-  double var = ss / (double)p.npix - mean * mean;
+  const long npix = p.npix * (p.stat_ranks > 1 ? p.stat_ranks : 1);      // cross-rank statistics: sums over all ranks' pixels
+  const double mean = s / (double)npix;
+  double var = ss / (double)npix - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
   const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
@@ -702,7 +727,7 @@ __device__ __forceinline__ void bn_finalize_channel(const hrseg_bn_fwd_t& p, int
     // stat_div > 1: the tensor holds stat_div identical copies of the pass's images (batched level
     // passes); mean and biased variance of the copies are those of one pass, the unbiased factor uses
     // one pass's pixel count
-    const long n1 = p.npix / (p.stat_div > 1 ? p.stat_div : 1);
+    const long n1 = npix / (p.stat_div > 1 ? p.stat_div : 1);
     const double unb = (n1 > 1) ? var * (double)n1 / (double)(n1 - 1) : var;
     float rv = p.running_var[c];
     for (int r = 0; r < reps; ++r) rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
@@ -785,6 +810,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
     if (seg) __syncthreads();                                   // red is reused
     reduce_chunks16(p.partial + (size_t)seg * cps * 2 * C, cps, C, c, s, sx, red);
     if (threadIdx.x < 16 && c < C) {
+      if (p.sum_ranks > 1) {               // sums over all ranks -> this rank's share (means stay global: the apply divides by the local count)
+        s /= (double)p.sum_ranks;
+        sx /= (double)p.sum_ranks;
+      }
       totals[(size_t)seg * 2 * C + c] = s;
       totals[(size_t)seg * 2 * C + C + c] = sx;
       s_all += s;
@@ -1021,6 +1050,14 @@ extern "C" int hrseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz
   return 0;
 }
 
+extern "C" int hrseg_absmax(const float* x, int ldx, long npix, int C, float* out64, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_absmax")) return e;
+  HRSEG_CHECK_ARG(x && out64 && npix > 0 && ldx >= C, "hrseg_absmax: bad arguments");
+  hipLaunchKernelGGL(absmax_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, x, ldx, npix, C, out64);
+  HRSEG_LAUNCH_CHECK("absmax");
+  return 0;
+}
+
 extern "C" int hrseg_nchw_to_nhwc(const float* in, float* out, int ldout, int B, int C, int H, int W,
                                   hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(in && out && B > 0 && C > 0 && ldout >= C, "hrseg_nchw_to_nhwc: bad arguments");
@@ -1096,7 +1133,12 @@ static int check_bn_fwd(const hrseg_bn_fwd_t& p, int training) {
 }
 
 extern "C" int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* probs, int training, hrseg_stream_t stream) {
+  return hrseg_bn_fwd_group_phases(n, probs, training, 7, stream);
+}
+
+extern "C" int hrseg_bn_fwd_group_phases(int n, const hrseg_bn_fwd_t* probs, int training, int phases, hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(n >= 1 && n <= BN_MAXG && probs, "hrseg_bn_fwd_group: n must be 1..%d", BN_MAXG);
+  HRSEG_CHECK_ARG(phases > 0 && phases <= 7, "hrseg_bn_fwd_group_phases: phases is a mask of bits 0..2");
   hipStream_t st = (hipStream_t)stream;
   BnFwdG g;
   g.h.n = n;
@@ -1106,27 +1148,38 @@ extern "C" int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* probs, int traini
   }
   int end = 0;
   if (training) {
-    for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-    hipLaunchKernelGGL(bn_stats_group_kernel, dim3(end), dim3(256), 0, st, g);
-    HRSEG_LAUNCH_CHECK("bn_stats_group");
-    end = 0;
-    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
-    hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
-    HRSEG_LAUNCH_CHECK("bn_finalize_group");
-  } else {
+    if (phases & 1) {
+      for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
+      hipLaunchKernelGGL(bn_stats_group_kernel, dim3(end), dim3(256), 0, st, g);
+      HRSEG_LAUNCH_CHECK("bn_stats_group");
+    }
+    if (phases & 2) {
+      end = 0;
+      for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+      hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+      HRSEG_LAUNCH_CHECK("bn_finalize_group");
+    }
+  } else if (phases & 2) {
     for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 64); g.h.blk_end[i] = end; }
     hipLaunchKernelGGL(bn_eval_coef_group_kernel, dim3(end), dim3(64), 0, st, g);
     HRSEG_LAUNCH_CHECK("bn_eval_coef_group");
   }
-  end = 0;
-  for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
-  hipLaunchKernelGGL(bn_apply_group_kernel, dim3(end), dim3(256), 0, st, g);
-  HRSEG_LAUNCH_CHECK("bn_apply_group");
+  if (phases & 4) {
+    end = 0;
+    for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_apply_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_apply_group");
+  }
   return 0;
 }
 
 extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_mode, hrseg_stream_t stream) {
+  return hrseg_bn_bwd_group_phases(n, probs, eval_mode, 7, stream);
+}
+
+extern "C" int hrseg_bn_bwd_group_phases(int n, const hrseg_bn_bwd_t* probs, int eval_mode, int phases, hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(n >= 1 && n <= BN_MAXG && probs, "hrseg_bn_bwd_group: n must be 1..%d", BN_MAXG);
+  HRSEG_CHECK_ARG(phases > 0 && phases <= 7, "hrseg_bn_bwd_group_phases: phases is a mask of bits 0..2");
   hipStream_t st = (hipStream_t)stream;
   BnBwdG g;
   g.h.n = n;
@@ -1140,16 +1193,22 @@ extern "C" int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* probs, int eval_m
     g.p[i] = p;
   }
   int end = 0;
-  for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-  hipLaunchKernelGGL(bn_bwd_reduce_group_kernel, dim3(end), dim3(256), 0, st, g);
-  HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
-  end = 0;
-  for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
-  hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
-  HRSEG_LAUNCH_CHECK("bn_bwd_finalize_group");
-  end = 0;
-  for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
-  hipLaunchKernelGGL(bn_bwd_apply_group_kernel, dim3(end), dim3(256), 0, st, g, eval_mode);
-  HRSEG_LAUNCH_CHECK("bn_bwd_apply_group");
+  if (phases & 1) {
+    for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_bwd_reduce_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
+  }
+  if (phases & 2) {
+    end = 0;
+    for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);
+    HRSEG_LAUNCH_CHECK("bn_bwd_finalize_group");
+  }
+  if (phases & 4) {
+    end = 0;
+    for (int i = 0; i < n; ++i) { end += elem_grid(probs[i].npix, probs[i].C); g.h.blk_end[i] = end; }
+    hipLaunchKernelGGL(bn_bwd_apply_group_kernel, dim3(end), dim3(256), 0, st, g, eval_mode);
+    HRSEG_LAUNCH_CHECK("bn_bwd_apply_group");
+  }
   return 0;
 }

@@ -19,13 +19,29 @@
 //    one (tap, cout tile, cin tile) and a pixel range, its 4 waves split the
 //    pixels, reduce through LDS and add into dW with fp32 atomics (dW holds
 //    the running gradient of the step, so the add IS the accumulation).
-//  * Cin <= 4 (the image layer): direct VALU kernels.
+//  * Cin <= 8 (the image layer; with logit-concatenated re-encoding image + previous level's logits): direct VALU
+//    kernels (conv_small.hip).
 //
 // This file holds the dispatch (tile plans, kernel-family choice per problem) and the C ABI; the kernel families
 // and their launchers live in conv_f32.hip, conv_wgrad_f32.hip, conv_sp_im2col.hip, conv_sp_patch.hip,
 // conv_sp_pgroup.hip, conv_ws.hip and conv_wgrad_sp.hip (split for build time; conv_common.h declares the launchers).
 #include "conv_common.h"
 #include "conv_sp.h"
+#include <mutex>
+
+// launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
+// it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
+enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_N };
+static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin"};
+static long g_cnt[CNT_N];
+extern "C" long hrseg_launch_count(const char* family, int reset) {
+  long total = 0;
+  for (int i = 0; i < CNT_N; ++i)
+    if (!family || !strcmp(family, g_cnt_names[i])) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+  return total;
+}
 
 // tuning overrides (hrseg_tune, 0 = automatic): pixel tiles per wave, K chunks, LDS buffers, split-K
 static int g_tune_wtm = 0, g_tune_kc = 0, g_tune_db = 0, g_tune_ksplit = 0;
@@ -127,6 +143,9 @@ static SpPlan plan_sp(const IgemmArgs& a) {
 
 // halo-patch body: full 3x3 stride-1 problems (forward or data gradient) on images wide enough that the
 // 8 x 16 tiles waste little and fill the chip; returns the chunks per K stage (3 or 4), 0 = not a patch case
+// routing thresholds (hrseg_tune keys sp_patch_min_tiles, auto_min_pixels, sp_ws_min_tiles): the parity tests lower them so that
+// the small golden cases run the kernels the headline sizes run
+static int g_patch_min_tiles = 192, g_auto_min_pix = 8192, g_ws_min_tiles = 96;
 static int g_sp_patch = 1;              // hrseg_tune "sp_patch": 0 = never use the patch body
 // tap geometry of a full 3x3 stride-1 problem: 0 = forward (tap t reads offset (t/3-1, t%3-1)), 1 = data gradient
 // (offset (1-t/3, 1-t%3)), -1 = neither; the weight tap index must be t
@@ -149,7 +168,7 @@ static int patch_cs(const IgemmArgs& a, int wtn) {
   if (!cs) return 0;
   const long tiles = (long)a.B * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 16);
   const double waste = (double)(ceil_div(a.Ho, 8) * 8) * (ceil_div(a.Wo, 16) * 16) / ((double)a.Ho * a.Wo);
-  if (waste > 1.22 || tiles * (a.N / (16 * wtn)) < 192) return 0;
+  if (waste > 1.22 || tiles * (a.N / (16 * wtn)) < g_patch_min_tiles) return 0;
   return cs;
 }
 static long patch_tiles(const IgemmArgs& a, int wtn) {
@@ -165,19 +184,33 @@ static int g_ws_n48 = 1;                // hrseg_tune "sp_ws_n48": 0 = 48-channe
 static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile padding accepted, percent of the image
 static unsigned char* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
+static int g_scratch_device = -1;       // the device that was current when the buffer was attached: launches on another one do not use it
+static std::mutex g_scratch_mu;         // the region table is the only mutable state the launch path shares between host threads
 struct ScratchRegion { hipStream_t st; bool used; size_t head; };
 static const int SCRATCH_REGIONS = 8;
 static ScratchRegion g_regions[SCRATCH_REGIONS];
 extern "C" int hrseg_set_scratch(void* ptr, size_t bytes) {
   HRSEG_CHECK_ARG((ptr && bytes >= (1u << 20)) || (!ptr && bytes == 0), "hrseg_set_scratch: need a buffer of at least 1 MiB, or (null, 0)");
   HRSEG_CHECK_ARG(((uintptr_t)ptr & 255) == 0, "hrseg_set_scratch: the buffer must be 256-byte aligned");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
   g_scratch = (unsigned char*)ptr;
   g_scratch_bytes = bytes;
+  g_scratch_device = -1;
+  if (ptr && hipGetDevice(&g_scratch_device) != hipSuccess) g_scratch_device = -1;
   for (auto& r : g_regions) r = ScratchRegion{nullptr, false, 0};
   return 0;
 }
-static unsigned char* scratch_alloc(hipStream_t st, size_t bytes) {
-  if (!g_scratch) return nullptr;
+static bool scratch_usable() {
+  if (!g_scratch) return false;
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess && dev == g_scratch_device;
+}
+// `bytes` CONTIGUOUS bytes of this stream's ring.  All images of one grouped launch are reserved together: they are written by one
+// kernel and read by the next, so a wrap between two of them would put a later image over an earlier one of the same launch.
+// nullptr: no buffer (or one of another device), no free region for a ninth stream, or more than a region holds.
+static unsigned char* scratch_reserve(hipStream_t st, size_t bytes) {
+  if (!scratch_usable()) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
   const size_t region = (g_scratch_bytes / SCRATCH_REGIONS) & ~(size_t)255;
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes > region) return nullptr;
@@ -187,7 +220,7 @@ static unsigned char* scratch_alloc(hipStream_t st, size_t bytes) {
   for (int i = 0; i < SCRATCH_REGIONS && r < 0; ++i)
     if (!g_regions[i].used) { g_regions[i] = ScratchRegion{st, true, 0}; r = i; }
   if (r < 0) return nullptr;
-  if (g_regions[r].head + bytes > region) g_regions[r].head = 0;
+  if (g_regions[r].head + bytes > region) g_regions[r].head = 0;       // wrap BEFORE the group, never inside it
   unsigned char* p = g_scratch + (size_t)r * region + g_regions[r].head;
   g_regions[r].head += bytes;
   return p;
@@ -203,7 +236,7 @@ static double ws_waste(const IgemmArgs& a, int kind) {
   return (double)(ceil_div(a.Ho, WS_TH[kind]) * WS_TH[kind]) * (ceil_div(a.Wo, 16) * 16) / ((double)a.Ho * a.Wo);
 }
 static int ws_kind(const IgemmArgs& a) {
-  if (!g_sp_ws || !g_scratch || patch_flip(a) < 0 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
+  if (!g_sp_ws || !scratch_usable() || patch_flip(a) < 0 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
     return 0;
   if (a.oy_min != -1 || a.ox_min != -1) return 0;
   int kind = (a.K % 48 == 0 && a.N % 48 == 0) ? 1 : (a.K % 64 == 0 && a.N % 64 == 0) ? 3 : 0;
@@ -224,10 +257,16 @@ static size_t ws_image_bytes(const IgemmArgs& a, int kind) {
 static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st) {
   WeightImageGroup g;
   g.n = n;
+  size_t off[MAXG], total = 0;
+  for (int i = 0; i < n; ++i) {
+    off[i] = total;
+    total += (ws_image_bytes(a[i], kinds[i]) + 255) & ~(size_t)255;
+  }
+  unsigned char* base = scratch_reserve(st, total);
+  if (!base) return false;
   int end = 0;
   for (int i = 0; i < n; ++i) {
-    unsigned char* img = scratch_alloc(st, ws_image_bytes(a[i], kinds[i]));
-    if (!img) return false;
+    unsigned char* img = base + off[i];
     const int wtn = WS_WTN[kinds[i]], cs = WS_CS[kinds[i]];
     end += (a[i].N / (16 * wtn)) * (a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
     g.blk_end[i] = end;
@@ -247,6 +286,7 @@ static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
+  ++g_cnt[CNT_WS];
   return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st);
 }
 // One launch for several problems: the 256 persistent blocks are divided among the problems in proportion to their
@@ -296,6 +336,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     g.kind[i] = kinds[i];
     g.a[i] = a[i];
   }
+  ++g_cnt[CNT_WS_GROUP];
   return launch_ws_group_kernel(g, flip, st);
 }
 
@@ -315,11 +356,12 @@ static int launch_patch_sp(int ns, const IgemmArgs& a_in, int wtn, int cs, hipSt
     int kind = (wtn == 3 && cs == 3) ? 1 : (wtn == 6 && cs == 3) ? 2 : (wtn == 4 && cs == 4) ? 3 : 0;
     if (kind) ws_make_images(&a, &kind, 1, st);      // (no scratch space: a.wimg stays null)
   }
+  ++g_cnt[CNT_PATCH_SP];
   return launch_patch_sp_kernel(ns, a, wtn, cs, flip, blocks, ntotal, st);
 }
 
 static int launch_sp(int ns, const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
-  if (launch_sp_kernel(ns, a, pl, st) == 0) return 0;
+  if (launch_sp_kernel(ns, a, pl, st) == 0) { ++g_cnt[CNT_SP_IM2COL]; return 0; }
   hrseg_set_error("igemm_sp: no kernel for plan wtm=%d wtn=%d", pl.wtm, pl.wtn);
   return HRSEG_ERR_UNSUPPORTED;
 }
@@ -344,9 +386,9 @@ static void set_sp_scales(IgemmArgs& a, int precision, const float* grad_absmax)
 // the small ones; weight gradients: fp16x2 throughout
 static int resolve_auto(const IgemmArgs& a, int precision) {
   if (precision != HRSEG_CONV_AUTO) return precision;
-  if (a.M >= 8192) return HRSEG_CONV_FP16X2;
+  if (a.M >= g_auto_min_pix) return HRSEG_CONV_FP16X2;
   const int k = ws_kind(a);           // the wave-specialised patch body also wins on small images
-  return (k && ws_tiles(a, k) >= 96) ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
+  return (k && ws_tiles(a, k) >= g_ws_min_tiles) ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
 }
 
 static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
@@ -357,7 +399,7 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
     const SpPlan pl = plan_sp(a);
     if (ns == 4 && !g_sp_wtn) {
       const int kind = ws_kind(a);
-      if (kind && ws_tiles(a, kind) >= 96 && launch_ws_single(a, kind, st) == 0) return 0;
+      if (kind && ws_tiles(a, kind) >= g_ws_min_tiles && launch_ws_single(a, kind, st) == 0) return 0;
     }
     if (const int cs = patch_cs(a, pl.wtn)) {
       const int rc = launch_patch_sp(ns, a, pl.wtn, cs, st);
@@ -368,7 +410,7 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
   }
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
-  if (launch_igemm_f32(a, pl, st) == 0) return 0;
+  if (launch_igemm_f32(a, pl, st) == 0) { ++g_cnt[CNT_F32]; return 0; }
   hrseg_set_error("igemm: no kernel for plan wtm=%d wtn=%d kc=%d db=%d", pl.wtm, pl.wtn, pl.kc, pl.db);
   return HRSEG_ERR_UNSUPPORTED;
 }
@@ -398,8 +440,10 @@ static int launch_sp_group(int ns, const IgemmGroup& g_in, int wtm, int wtn, int
         if (flip >= 0 && f != flip) return 1;
         flip = f;
       }
+    ++g_cnt[CNT_SP_PGROUP];
     return launch_sp_pgroup_kernel(ns, g, wtm, wtn, cs, flip, st);
   }
+  ++g_cnt[CNT_SP_GROUP];
   return launch_sp_group_kernel(ns, g, wtm, wtn, full, st);
 }
 
@@ -407,8 +451,10 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
 // HRSEG_CONV_AUTO on a group: the problems the halo-patch body takes go out as one fp16x2 launch (a
 // low-resolution branch inside a patch launch would run at the patch body's occupancy); of the rest, the small ones
 // (< 8192 pixels) as one fp32 launch and the others one by one
+// Contract of the group dispatchers: 1 = nothing was launched (the caller issues the problems one by one), 0 = all launched,
+// negative = hard error after some launches went out (the caller must NOT re-issue: accumulating problems would add twice)
 static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, bool try_ws = true) {
-  if (try_ws && g_sp_ws && g_scratch && !g_sp_wtn) {
+  if (try_ws && g_sp_ws && scratch_usable() && !g_sp_wtn) {
     // the problems the wave-specialised body takes go out as one launch of 256 persistent blocks; the rest as before
     IgemmArgs wsa[MAXG], rest[MAXG];
     int kinds[MAXG], nw = 0, nr = 0;
@@ -416,7 +462,7 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
       IgemmArgs f = a[i];
       if (finalize_args(f)) return 1;
       const int k = ws_kind(f);
-      if (k && ws_tiles(f, k) >= 96) { wsa[nw] = f; kinds[nw++] = k; }
+      if (k && ws_tiles(f, k) >= g_ws_min_tiles) { wsa[nw] = f; kinds[nw++] = k; }
       else rest[nr++] = a[i];
     }
     // (a lone taker next to a 48-channel high-resolution branch: the two share one halo-patch group launch instead,
@@ -428,10 +474,10 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
     }
     if (nw >= 1 && !pair && launch_ws_group(wsa, kinds, nw, st) == 0) {
       if (nr == 0) return 0;
-      if (nr == 1) { const int e = dispatch_igemm(rest[0], HRSEG_CONV_AUTO, st); return e < 0 ? e : (e ? 1 : 0); }
+      if (nr == 1) { const int e = dispatch_igemm(rest[0], HRSEG_CONV_AUTO, st); return e < 0 ? e : (e ? HRSEG_ERR_LAUNCH : 0); }
       if (dispatch_igemm_group_auto(rest, nr, st, false) == 0) return 0;
       for (int i = 0; i < nr; ++i)
-        if (int e = dispatch_igemm(rest[i], HRSEG_CONV_AUTO, st)) return e < 0 ? e : 1;
+        if (int e = dispatch_igemm(rest[i], HRSEG_CONV_AUTO, st)) return e < 0 ? e : HRSEG_ERR_LAUNCH;
       return 0;
     }
   }
@@ -446,24 +492,24 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
   }
   if (nh == 0) {
     bool small = true, large = true;
-    for (int i = 0; i < n; ++i) { small = small && a[i].M < 8192; large = large && a[i].M >= 8192; }
+    for (int i = 0; i < n; ++i) { small = small && a[i].M < g_auto_min_pix; large = large && a[i].M >= g_auto_min_pix; }
     if (small) return dispatch_igemm_group(a, n, HRSEG_CONV_F32, st);
     if (large) return dispatch_igemm_group(a, n, HRSEG_CONV_FP16X2, st);
   }
   int rc = (nh >= 2) ? dispatch_igemm_group(hi, nh, HRSEG_CONV_FP16X2, st) : 1;
   if (rc != 0)
     for (int i = 0; i < nh; ++i)
-      if (int e = dispatch_igemm(hi[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : 1;
+      if (int e = dispatch_igemm(hi[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : HRSEG_ERR_LAUNCH;
   IgemmArgs sm[MAXG];
   int nsm = 0;
   for (int i = 0; i < nl; ++i) {
-    if (lo[i].M < 8192) { sm[nsm++] = lo[i]; continue; }
-    if (int e = dispatch_igemm(lo[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : 1;
+    if (lo[i].M < g_auto_min_pix) { sm[nsm++] = lo[i]; continue; }
+    if (int e = dispatch_igemm(lo[i], HRSEG_CONV_FP16X2, st)) return e < 0 ? e : HRSEG_ERR_LAUNCH;
   }
   rc = (nsm >= 2) ? dispatch_igemm_group(sm, nsm, HRSEG_CONV_F32, st) : 1;
   if (rc != 0)
     for (int i = 0; i < nsm; ++i)
-      if (int e = dispatch_igemm(sm[i], HRSEG_CONV_F32, st)) return e < 0 ? e : 1;
+      if (int e = dispatch_igemm(sm[i], HRSEG_CONV_F32, st)) return e < 0 ? e : HRSEG_ERR_LAUNCH;
   return 0;
 }
 
@@ -528,132 +574,8 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     g.a[o] = fa[i];
   }
   if (ns) return launch_sp_group(ns, g, wtm, wtn, group_cs, st);
+  ++g_cnt[CNT_F32_GROUP];
   return launch_igemm_group_f32(g, wtm, wtn, kc, st);
-}
-
-// --------------------------------------------------------------------------- direct conv, Cin <= 4
-// y[b,oy,ox,co] = bias[co] + sum_{t,ci} x[b, oy*s+kh-1, ox*s+kw-1, ci] * w[co][t][ci]
-// one thread = one output pixel x 16 channels; weights of the block's 64 channels in LDS.
-__global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __restrict__ x, int ldx,
-                                                                 const float* __restrict__ w,
-                                                                 const float* __restrict__ bias,
-                                                                 float* __restrict__ y, int ldy, int B, int Hi,
-                                                                 int Wi, int Cin, int Ho, int Wo, int Cout,
-                                                                 int ks, int stride) {
-  __shared__ float wl[64 * 9 * 4];
-  const int T = ks * ks, pad = (ks - 1) / 2;
-  const int cb = blockIdx.y * 64;  // channel block
-  for (int i = threadIdx.x; i < 64 * T * Cin; i += 256) {
-    const int co = i / (T * Cin);
-    wl[i] = (cb + co < Cout) ? w[(size_t)(cb + co) * T * Cin + (i - co * T * Cin)] : 0.f;
-  }
-  __syncthreads();
-  const long M = (long)B * Ho * Wo;
-  const long m = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int cg = threadIdx.x >> 6;  // 16-channel group
-  if (m >= M) return;
-  const int b = (int)(m / ((long)Ho * Wo));
-  const int rem = (int)(m - (long)b * Ho * Wo);
-  const int oy = rem / Wo, ox = rem - oy * Wo;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
-    if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-    const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float xv = xp[ci];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = fmaf(xv, wl[((cg * 16 + j) * T + t) * Cin + ci], acc[j]);
-    }
-  }
-  float* yp = y + (size_t)m * ldy + cb + cg * 16;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int co = cb + cg * 16 + j;
-    if (co < Cout) yp[j] = acc[j] + (bias ? bias[co] : 0.f);
-  }
-}
-
-// dw[co][t][ci] += sum_pix dy[pix][co] * x[pix_t][ci]; thread = (co, tap group), block = pixel range
-__global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* __restrict__ x, int ldx,
-                                                                   const float* __restrict__ dy, int lddy,
-                                                                   float* __restrict__ dw, int B, int Hi,
-                                                                   int Wi, int Cin, int Ho, int Wo, int Cout,
-                                                                   int ks, int stride, int pix_per_block) {
-  // Block = 64 output channels x a pixel range, walked in 64-pixel stages through LDS: all 256
-  // threads stage the dy tile [64 pix][64 co] and the gathered input taps [64 pix][T][4] with
-  // independent loads (memory-level parallelism instead of a serial per-pixel loop), then thread
-  // (co, tap group tg: taps tg, tg+4, tg+8) runs the 64-pixel FMA loop out of LDS (dy: conflict-free,
-  // x: broadcast).  One atomic per weight per block; the grid keeps blocks x weights small.
-  constexpr int P = 64;
-  __shared__ __attribute__((aligned(16))) float dys[P][64];
-  __shared__ __attribute__((aligned(16))) float xs[P][12][4];
-  const int T = ks * ks, pad = (ks - 1) / 2;
-  const int tid = threadIdx.x;
-  const int co0 = blockIdx.y * 64, co = co0 + (tid & 63);
-  const int tg = tid >> 6;
-  const int M = B * Ho * Wo, hw = Ho * Wo;
-  const int lo = blockIdx.x * pix_per_block;
-  const int hi = min(lo + pix_per_block, M);
-  float acc[3][4];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
-  for (int s0 = lo; s0 < hi; s0 += P) {
-    // dy tile: thread -> (pixel j>>4, 4 channels (j&15)*4)
-#pragma unroll
-    for (int r = 0; r < (P * 16) / 256; ++r) {
-      const int j = tid + 256 * r;
-      const int pp = j >> 4, c4 = (j & 15) * 4;
-      const int m = s0 + pp;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < hi) {
-        const float* src = dy + (size_t)m * lddy + co0 + c4;
-        if (co0 + c4 + 3 < Cout && (lddy & 3) == 0) v = *reinterpret_cast<const f32x4*>(src);
-        else
-          for (int e = 0; e < 4; ++e) if (co0 + c4 + e < Cout) v[e] = src[e];
-      }
-      *reinterpret_cast<f32x4*>(&dys[pp][c4]) = v;
-    }
-    // input taps: item -> (pixel, tap)
-    for (int j = tid; j < P * T; j += 256) {
-      const int pp = j / T, t = j - pp * T;
-      const int m = s0 + pp;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < hi) {
-        const int b = m / hw, rem = m - b * hw;
-        const int oy = rem / Wo, ox = rem - oy * Wo;
-        const int iy = oy * stride + t / ks - pad, ix = ox * stride + t % ks - pad;
-        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
-          const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
-          for (int c = 0; c < Cin; ++c) v[c] = xp[c];
-        }
-      }
-      *reinterpret_cast<f32x4*>(&xs[pp][t][0]) = v;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int pp = 0; pp < P; ++pp) {
-      const float g = dys[pp][tid & 63];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[pp][tg + 4 * a][0]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(g, xv[c], acc[a][c]);
-      }
-    }
-    __syncthreads();
-  }
-  if (co >= Cout) return;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int t = tg + 4 * a;
-    if (t >= T) continue;
-    for (int c = 0; c < Cin; ++c) atomicAdd(dw + ((size_t)co * T + t) * Cin + c, acc[a][c]);
-  }
 }
 
 static int g_tune_wg_pix = 0, g_tune_wg_db = 0, g_tune_wg_blocks = 0;
@@ -684,6 +606,7 @@ static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
   a.pix_per_block = ppb;
   if (int e = check_wgrad_span(a)) return e;
   const int gx = ceil_div(a.M, ppb);
+  ++g_cnt[CNT_WGRAD_SP];
   return launch_wgrad_sp_kernel(ns, a, tn, tk, gx, tiles, st);
 }
 
@@ -724,6 +647,7 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
     g.blk_end[i] = end;
     g.a[i] = a[i];
   }
+  ++g_cnt[CNT_WGRAD_F32_GROUP];
   return launch_wgrad_group_f32(g, tn, tk, end, st);
 }
 
@@ -787,6 +711,7 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
     r.blk_end[i] = rend;
     ws += (size_t)a.nchunks * elems;
   }
+  ++g_cnt[CNT_WGRAD9];
   return launch_wgrad9_kernels(ns, tnk, g, end, r, rend, st);
 }
 
@@ -925,7 +850,9 @@ extern "C" int hrseg_conv_fwd_group(int n, const float* const* x, const float* c
   if (ok && n >= 2) {
     IgemmArgs a[MAXG];
     for (int i = 0; i < n; ++i) fill_fwd_args(a[i], x[i], w[i], bias ? bias[i] : nullptr, y[i], &shapes[i]);
-    if (dispatch_igemm_group(a, n, shapes[0].precision, st) == 0) {
+    const int rc = dispatch_igemm_group(a, n, shapes[0].precision, st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
       HRSEG_LAUNCH_CHECK("igemm_group(fwd)");
       return 0;
     }
@@ -948,7 +875,9 @@ extern "C" int hrseg_conv_dgrad_group(int n, const float* const* dy, const float
   if (ok && n >= 2) {
     IgemmArgs a[MAXG];
     for (int i = 0; i < n; ++i) fill_dgrad_s1_args(a[i], dy[i], wt[i], dx[i], accumulate[i], &shapes[i]);
-    if (dispatch_igemm_group(a, n, shapes[0].precision, st) == 0) {
+    const int rc = dispatch_igemm_group(a, n, shapes[0].precision, st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
       HRSEG_LAUNCH_CHECK("igemm_group(dgrad)");
       return 0;
     }
@@ -1011,12 +940,11 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   if (int e = check_shape(s, "hrseg_conv_fwd")) return e;
   HRSEG_CHECK_ARG(x && w && y, "hrseg_conv_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  HRSEG_CHECK_ARG(s->Cout % 16 == 0 || s->Cin <= 4, "hrseg_conv_fwd: Cout %d not a multiple of 16", s->Cout);
-  if (s->Cin <= 4) {
+  HRSEG_CHECK_ARG(s->Cout % 16 == 0 || s->Cin <= HRSEG_SMALL_CIN_MAX, "hrseg_conv_fwd: Cout %d not a multiple of 16", s->Cout);
+  if (s->Cin <= HRSEG_SMALL_CIN_MAX) {
     const long M = (long)s->B * s->Ho * s->Wo;
-    dim3 grid(ceil_div(M, 64), ceil_div(s->Cout, 64));
-    hipLaunchKernelGGL(conv_small_cin_fwd_kernel, grid, dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B, s->Hi,
-                       s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride);
+    launch_small_cin_fwd(x, w, bias, y, s, st);
+    ++g_cnt[CNT_SMALL_CIN];
     HRSEG_LAUNCH_CHECK("conv_small_cin_fwd");
     return 0;
   }
@@ -1043,6 +971,13 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
                                 const hrseg_conv_shape_t* s, hrseg_stream_t stream) {
   if (int e = check_shape(s, "hrseg_conv_dgrad")) return e;
   HRSEG_CHECK_ARG(dy && wt && dx, "hrseg_conv_dgrad: null pointer");
+  if (s->Cin <= HRSEG_SMALL_CIN_MAX) {
+    // first layer with a differentiable input (logit-concatenated re-encoding): `wt` is the FORWARD weight [Cout][k*k][Cin]
+    launch_small_cin_dgrad(dy, wt, dx, accumulate, s, (hipStream_t)stream);
+    ++g_cnt[CNT_SMALL_CIN];
+    HRSEG_LAUNCH_CHECK("conv_small_cin_dgrad");
+    return 0;
+  }
   HRSEG_CHECK_ARG(s->Cin % 16 == 0 && s->Cout % 16 == 0, "hrseg_conv_dgrad: channels (%d,%d) must be multiples of 16",
                   s->Cin, s->Cout);
   HRSEG_CHECK_ARG(s->ldx % 4 == 0 && s->ldy % 4 == 0, "hrseg_conv_dgrad: ld must be a multiple of 4");
@@ -1088,9 +1023,13 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
       pack_taps(c, n, oy, ox, wtp);
       cls[ncls++] = c;
     }
-  if (ncls >= 2 && dispatch_igemm_group(cls, ncls, s->precision, st) == 0) {
-    HRSEG_LAUNCH_CHECK("igemm_group(dgrad s2)");
-    return 0;
+  if (ncls >= 2) {
+    const int rc = dispatch_igemm_group(cls, ncls, s->precision, st);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      HRSEG_LAUNCH_CHECK("igemm_group(dgrad s2)");
+      return 0;
+    }
   }
   for (int i = 0; i < ncls; ++i) {
     if (int e = dispatch_igemm(cls[i], s->precision, st)) return e;
@@ -1109,15 +1048,14 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
   HRSEG_CHECK_ARG(x && dy && dw, "hrseg_conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int T = s->ksize * s->ksize;
-  if (s->Cin <= 4) {
+  if (s->Cin <= HRSEG_SMALL_CIN_MAX) {
     const long M = (long)s->B * s->Ho * s->Wo;
     // ~512 blocks (measured, tools/misc_bench.py): every block adds into the same Cout*T*Cin
     // addresses, ~0.35 us of serialized atomics per block; fewer blocks leave CUs idle
     const int nblk_target = hrseg_g_deterministic ? 1 : g_tune_wg_blocks ? g_tune_wg_blocks : 512;
     int ppb = (int)ceil_div(ceil_div(M, nblk_target), 64) * 64;
-    dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
-    hipLaunchKernelGGL(conv_small_cin_wgrad_kernel, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi,
-                       s->Wi, s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, ppb);
+    launch_small_cin_wgrad(x, dy, dw, s, ppb, st);
+    ++g_cnt[CNT_SMALL_CIN];
     HRSEG_LAUNCH_CHECK("conv_small_cin_wgrad");
     return 0;
   }
@@ -1150,6 +1088,7 @@ extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, cons
     if (g_tune_wg_db) db = g_tune_wg_db;
     if (g_tune_wg_blocks) target = g_tune_wg_blocks;
     if (int e = launch_wgrad_f32(a, tn, tk, pix, db, target, st)) return e;
+    ++g_cnt[CNT_WGRAD_F32];
   }
   HRSEG_LAUNCH_CHECK("wgrad");
   return 0;
@@ -1186,10 +1125,17 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
       {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks},
+      {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");
   for (auto& e : tab)
-    if (!strcmp(e.k, key)) { *e.v = value; return 0; }
+    if (!strcmp(e.k, key)) {
+      *e.v = value;
+      if (g_patch_min_tiles <= 0) g_patch_min_tiles = 192;      // (0 = the default plan, as for every key)
+      if (g_auto_min_pix <= 0) g_auto_min_pix = 8192;
+      if (g_ws_min_tiles <= 0) g_ws_min_tiles = 96;
+      return 0;
+    }
   hrseg_set_error("hrseg_tune: unknown key '%s'", key);
   return HRSEG_ERR_INVALID_ARG;
 }

@@ -112,4 +112,8 @@ int launch_ws_group_kernel(const IgemmGroup& g, int flip, hipStream_t st);
 int launch_weight_images(const struct WeightImageGroup& g, int nblocks, hipStream_t st);
 int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, int tiles, hipStream_t st);     // conv_wgrad_sp.hip
 int launch_wgrad9_kernels(int ns, int tnk, const struct Wgrad9Group& g, int nblocks, const struct Wgrad9Reduce& r, int rblocks, hipStream_t st);
-int check_wgrad_span(const WgradArgs& a);                                                              // conv.hip
+int check_wgrad_span(const WgradArgs& a);
+#define HRSEG_SMALL_CIN_MAX 8
+void launch_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, const hrseg_conv_shape_t* s, hipStream_t st);  // conv_small.hip
+void launch_small_cin_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s, int pix_per_block, hipStream_t st);
+void launch_small_cin_dgrad(const float* dy, const float* w, float* dx, int accumulate, const hrseg_conv_shape_t* s, hipStream_t st);                                                              // conv.hip

@@ -81,7 +81,7 @@ template <int NS, int N>
 __device__ __forceinline__ void sp_split(float (&x)[N], unsigned (&out)[sp_np(NS)][N / 2], float sc) {
   if (NS == 4) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j] * sc, -65504.f, 65504.f);
+    for (int j = 0; j < N; ++j) x[j] *= sc;      // no clamp: NaN propagates, |x| beyond fp16 range ends in Inf / NaN (loud), see hrseg.h
 #pragma unroll
     for (int j = 0; j < N / 2; ++j) {
       const unsigned hi = sp_pack_f16_rtz(x[2 * j], x[2 * j + 1]);

@@ -701,6 +701,89 @@ __global__ void consistency_bwd_kernel(const float* __restrict__ p, const float*
     if (c < Cprev) dpprev[((size_t)b * Cprev + c) * hw + pix] = dpar[c];
 }
 
+// --------------------------------------------------------------------------- grouped conditional KL (opt-in stabiliser)
+// Restates the commented-out `grouped_conditional_kl` of the reference (Metrics/losses.py:180-210): per parent group g
+// of the level, Q = softmax_c(z_c + log(P_parent + 1e-6)).clamp_min(1e-8) over the group's children and
+// KL(Q || Uniform) = Q * (log Q - log(1/g)), `.mean()` over [B, g, H, W]; the level's value is the mean over its groups.
+// (The log-bias is the same for every child of a group, so Q = softmax(z) and P_parent receives no gradient.)
+// out[gi] += sum over pixels and children of Qc * (log Qc + log g), double.
+__global__ __launch_bounds__(256) void group_kl_kernel(const float* __restrict__ z, const float* __restrict__ pprev,
+                                                       double* __restrict__ out, int C, int Cprev, long hw, long n, Groups g) {
+  __shared__ float red[4][MAXC];
+  float acc[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) acc[k] = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / hw, pix = i - b * hw;
+    int start = 0;
+#pragma unroll
+    for (int gi = 0; gi < MAXC; ++gi)
+      if (gi < g.n) {
+        const int gs = g.size[gi];
+        const float lb = logf(pprev[((size_t)b * Cprev + g.parent[gi]) * hw + pix] + 1e-6f);
+        float v[MAXC], m = -INFINITY;
+        for (int c = 0; c < gs; ++c) {
+          v[c] = z[((size_t)b * C + start + c) * hw + pix] + lb;
+          m = fmaxf(m, v[c]);
+        }
+        float den = 0.f;
+        for (int c = 0; c < gs; ++c) { v[c] = expf(v[c] - m); den += v[c]; }
+        const float lg = logf((float)gs);
+        float kl = 0.f;
+        for (int c = 0; c < gs; ++c) {
+          const float q = fmaxf(v[c] / den, 1e-8f);
+          kl += q * (logf(q) + lg);
+        }
+        acc[gi] += kl;
+        start += gs;
+      }
+  }
+#pragma unroll
+  for (int gi = 0; gi < MAXC; ++gi) {
+    const float v = wave_sum(acc[gi]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][gi] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < g.n)
+    atomicAdd(out + threadIdx.x,
+              (double)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dz of  gup * sum_g scale_g * sum_{pix,c} Qc (log Qc + log g),  scale_g = scale / (size_g)  (the .mean() over the
+// channel dimension; `scale` carries 1 / (B*H*W*ngroups)).  With a_c = [Q_c >= 1e-8] (log Qc_c + 1 + log g):
+// dz_j = Q_j (a_j - sum_c a_c Q_c).
+__global__ void group_kl_bwd_kernel(const float* __restrict__ z, const float* __restrict__ pprev,
+                                    const float* __restrict__ gup, float scale, float* __restrict__ dz, int C, int Cprev,
+                                    long hw, long n, Groups g) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long b = i / hw, pix = i - b * hw;
+  const float gsc = gup[0] * scale;
+  int start = 0;
+  for (int gi = 0; gi < g.n; ++gi) {
+    const int gs = g.size[gi];
+    const float lb = logf(pprev[((size_t)b * Cprev + g.parent[gi]) * hw + pix] + 1e-6f);
+    float v[MAXC], m = -INFINITY;
+    for (int c = 0; c < gs; ++c) {
+      v[c] = z[((size_t)b * C + start + c) * hw + pix] + lb;
+      m = fmaxf(m, v[c]);
+    }
+    float den = 0.f;
+    for (int c = 0; c < gs; ++c) { v[c] = expf(v[c] - m); den += v[c]; }
+    const float lg = logf((float)gs);
+    float a[MAXC], dot = 0.f;
+    for (int c = 0; c < gs; ++c) {
+      const float q = v[c] / den;
+      v[c] = q;
+      a[c] = (q >= 1e-8f) ? (logf(q) + 1.f + lg) : 0.f;
+      dot += a[c] * q;
+    }
+    const float sc = gsc / (float)gs;
+    for (int c = 0; c < gs; ++c) dz[((size_t)b * C + start + c) * hw + pix] = sc * v[c] * (a[c] - dot);
+    start += gs;
+  }
+}
+
 // argmax one-hot (masked by t != -1) and confusion counts cm[target][pred]
 template <int CT>
 __global__ __launch_bounds__(256) void predict_metrics_kernel(const float* __restrict__ z, const float* __restrict__ t,
@@ -985,6 +1068,35 @@ extern "C" int hrseg_predict_metrics(const float* z, const float* t, float* oneh
   else if (C <= 8) hipLaunchKernelGGL((predict_metrics_kernel<8>), grid, dim3(256), 0, st, z, t, onehot, c, C, hw, n, child, mask_pred);
   else hipLaunchKernelGGL((predict_metrics_kernel<16>), grid, dim3(256), 0, st, z, t, onehot, c, C, hw, n, child, mask_pred);
   HRSEG_LAUNCH_CHECK("predict_metrics");
+  return 0;
+}
+
+extern "C" int hrseg_group_kl(const float* z, const float* pprev, double* out, int B, int C, int Cprev, long hw,
+                              int ngroups, const int* group_parent, const int* group_size, hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(z && pprev && out && B > 0 && C > 0 && C <= MAXC && Cprev > 0 && Cprev <= MAXC && hw > 0 && ngroups > 0,
+                  "hrseg_group_kl: bad arguments");
+  Groups g;
+  if (int e = fill_groups(g, ngroups, group_parent, group_size, C, Cprev, "hrseg_group_kl")) return e;
+  const long n = (long)B * hw;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (hrseg_g_deterministic) blocks = 1;
+  hipLaunchKernelGGL(group_kl_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, z, pprev, out, C, Cprev, hw, n, g);
+  HRSEG_LAUNCH_CHECK("group_kl");
+  return 0;
+}
+
+extern "C" int hrseg_group_kl_bwd(const float* z, const float* pprev, const float* g, float scale, float* dz, int B, int C,
+                                  int Cprev, long hw, int ngroups, const int* group_parent, const int* group_size,
+                                  hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(z && pprev && g && dz && B > 0 && C > 0 && C <= MAXC && Cprev > 0 && Cprev <= MAXC && hw > 0 && ngroups > 0,
+                  "hrseg_group_kl_bwd: bad arguments");
+  Groups gr;
+  if (int e = fill_groups(gr, ngroups, group_parent, group_size, C, Cprev, "hrseg_group_kl_bwd")) return e;
+  const long n = (long)B * hw;
+  hipLaunchKernelGGL(group_kl_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, z, pprev, g, scale, dz,
+                     C, Cprev, hw, n, gr);
+  HRSEG_LAUNCH_CHECK("group_kl_bwd");
   return 0;
 }
 

@@ -158,7 +158,8 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0):
+    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0, sync=None):
+        self.sync = sync                 # process group for cross-rank BatchNorm statistics (opt-in sync_bn), else None
         self.prec = prec                 # _lib.CONV_PRECISION code of every convolution of this forward (and its backward)
         self.training = training
         self.record = record
@@ -189,6 +190,8 @@ class Recorder:
                 fn()
 
     def _wt(self, conv):
+        if conv.in_channels <= 8:
+            return conv.weight._hr_store      # first layer: the direct data-gradient kernel reads the forward layout
         if self.flat is not None and hasattr(conv.weight, "_hr_tstore_range"):
             return self.flat.transposed(conv.weight)
         key = id(conv)
@@ -233,7 +236,7 @@ class Recorder:
                          stat_div=self.bn_segments,
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
-        zc = ops.bn_fwd_group(bn_items, self.training)
+        zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync)
         zs = [Act(z) for z, _ in zc]
         if not self.record:
             return zs
@@ -262,7 +265,7 @@ class Recorder:
                                dgamma=bn.weight._hr_gstore,
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments,
                                dy_absmax=gmaxs[i]))
-            dys = ops.bn_bwd_group(bw, eval_mode)
+            dys = ops.bn_bwd_group(bw, eval_mode, sync=self.sync)
             side = wgrad_stream(dys[0].device)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())

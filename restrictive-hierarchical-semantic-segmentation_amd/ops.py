@@ -76,10 +76,38 @@ def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None):
 
 
 # ------------------------------------------------------------------ convolution
+_F16_CODES = (_lib.CONV_PRECISION["auto"], _lib.CONV_PRECISION["fp16x2"])
+FP16X2_ACT_LIMIT = 65504.0
+
+
+def absmax(x):
+    """max|x| of an NHWC tensor as a 0-dim device tensor (NaN counts as +Inf): hrseg_absmax"""
+    slots = zeros((64,), torch.float32, x.device)
+    call("hrseg_absmax", ptr(x), _ld(x), _npix(x), x.shape[3], ptr(slots))
+    return slots.max()
+
+
+def _guard_prec(x, prec):
+    """fp16x2 convolutions take their activation operand unscaled (include/hrseg.h): exact up to |x| = 65504, Inf / NaN
+    results far beyond.  In deterministic mode (the verification mode: it may synchronise) the operand is range-checked
+    and an out-of-range or non-finite tensor runs the exact-fp32 kernels instead; counted in `range_fallbacks`."""
+    global range_fallbacks
+    if not _lib.deterministic() or prec not in _F16_CODES or x.shape[3] % 4 or torch.cuda.is_current_stream_capturing():
+        return prec            # (a captured graph cannot read a value back: the guard is an eager-mode check)
+    if float(absmax(x)) <= FP16X2_ACT_LIMIT:
+        return prec
+    range_fallbacks += 1
+    return _lib.CONV_PRECISION["f32"]
+
+
+range_fallbacks = 0
+
+
 def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
     pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions)."""
     _lib.ensure_scratch(x.device)
+    prec = _guard_prec(x, prec)
     B, Hi, Wi, Cin = x.shape
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
@@ -103,6 +131,7 @@ def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=N
 
 def conv_wgrad(x, dy, dw, k, s, prec=0, gmax=None):
     """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
+    prec = _guard_prec(x, prec)
     if prec and k == 3 and s == 1:
         return conv_wgrad_group([x], [dy], [dw], k, s, prec, [gmax])
     sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, gmax)
@@ -116,6 +145,8 @@ def _shape_array(shapes):
 def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
     """n independent convolutions (same k, s) in one launch when the library can group them"""
     _lib.ensure_scratch(xs[0].device)
+    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
+        prec = _lib.CONV_PRECISION["f32"]        # (one precision per grouped call)
     outs, shapes = [], []
     for x, co in zip(xs, couts):
         B, Hi, Wi, Cin = x.shape
@@ -143,6 +174,8 @@ def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=N
 
 
 def conv_wgrad_group(xs, dys, dws, k, s, prec=0, gmaxs=None):
+    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
+        prec = _lib.CONV_PRECISION["f32"]
     gm = gmaxs if gmaxs is not None else [None] * len(xs)
     shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, g) for x, dy, g in zip(xs, dys, gm)])
     nbytes = _lib.conv_wgrad_workspace_bytes(shapes, len(xs)) if (prec and k == 3 and s == 1) else 0
@@ -214,12 +247,25 @@ def bn_bwd(dz, z, relu, y, coef, dgamma, dbeta, dres=None, dres_accumulate=False
     return dy
 
 
-def bn_fwd_group(items, training):
+def _sync_world(sync):
+    import torch.distributed as dist
+    return dist.get_world_size(sync)
+
+
+def bn_fwd_group(items, training, sync=None):
     """items: list of dict(y, gamma, beta, rm, rv, nbt, momentum, eps, residual, relu[, out]);
-    -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply)."""
+    -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply).
+    sync (a process group, training only): cross-rank batch statistics -- the partial sums of all problems live in one
+    buffer that is all-reduced between the statistics and the finalize phase (opt-in synchronised BN)."""
     n = len(items)
     arr = (_lib.BnFwd * n)()
     outs = []
+    sync = sync if training else None
+    ranks = _sync_world(sync) if sync is not None else 1
+    pool, pool_off = None, 0
+    if sync is not None:
+        total = sum(_nchunks(_npix(it["y"]), it["y"].shape[3]) * 2 * it["y"].shape[3] for it in items)
+        pool = torch.empty(total, dtype=torch.float64, device=items[0]["y"].device)
     for a, it in zip(arr, items):
         y = it["y"]
         Cn, npix = y.shape[3], _npix(y)
@@ -237,24 +283,47 @@ def bn_fwd_group(items, training):
         a.stat_div = int(it.get("stat_div", 1))
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
+        a.stat_ranks = ranks
         if training:
             nch = _nchunks(npix, Cn)
-            part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
+            if pool is not None:
+                part = pool[pool_off:pool_off + nch * 2 * Cn]
+                pool_off += nch * 2 * Cn
+            else:
+                part = torch.empty(nch * 2 * Cn, dtype=torch.float64, device=y.device)
             a.partial, a.nchunks = ptr(part), nch
             outs.append((z, coef, part))
         else:
             a.partial, a.nchunks = None, 0
             outs.append((z, coef, None))
-    call("hrseg_bn_fwd_group", n, arr, int(training))
+    if sync is not None:
+        import torch.distributed as dist
+        call("hrseg_bn_fwd_group_phases", n, arr, 1, 1)
+        dist.all_reduce(pool, op=dist.ReduceOp.SUM, group=sync)
+        call("hrseg_bn_fwd_group_phases", n, arr, 1, 6)
+    else:
+        call("hrseg_bn_fwd_group", n, arr, int(training))
     return [(z, coef) for z, coef, _ in outs]
 
 
-def bn_bwd_group(items, eval_mode):
+def bn_bwd_group(items, eval_mode, sync=None):
     """items: list of dict(dz, z, relu, y, coef, dgamma, dbeta, dres, dres_accumulate); dy is written
-    in place over dz.  Three launches for the whole list."""
+    in place over dz.  Three launches for the whole list.  sync: see bn_fwd_group (the backward's batch means become
+    global; dgamma / dbeta receive this rank's share, so the gradient all-reduce sums them to the global value)."""
     n = len(items)
     arr = (_lib.BnBwd * n)()
     keep = []
+    sync = None if eval_mode else sync
+    ranks = _sync_world(sync) if sync is not None else 1
+    pool, pool_off = None, 0
+    if sync is not None:
+        total = 0
+        for it in items:
+            Cn, npix, nseg = it["y"].shape[3], _npix(it["y"]), int(it.get("nseg", 1))
+            nch = _nchunks(npix, Cn)
+            nch = max(nseg, nch // nseg * nseg) if nseg > 1 else nch
+            total += (nch + nseg) * 2 * Cn
+        pool = zeros((total,), torch.float64, items[0]["y"].device)
     for a, it in zip(arr, items):
         y, dz, z = it["y"], it["dz"], it["z"]
         Cn, npix = y.shape[3], _npix(y)
@@ -262,9 +331,14 @@ def bn_bwd_group(items, eval_mode):
         nch = _nchunks(npix, Cn)
         if nseg > 1:                                  # chunks never straddle two segments
             nch = max(nseg, nch // nseg * nseg)
-        part = torch.empty((nch + nseg) * 2 * Cn, dtype=torch.float64, device=y.device)
+        if pool is not None:
+            part = pool[pool_off:pool_off + (nch + nseg) * 2 * Cn]
+            pool_off += (nch + nseg) * 2 * Cn
+        else:
+            part = torch.empty((nch + nseg) * 2 * Cn, dtype=torch.float64, device=y.device)
         keep.append(part)
         a.nseg = nseg
+        a.sum_ranks = ranks
         dres = it.get("dres")
         a.dz, a.lddz = ptr(dz), _ld(dz)
         use_z = it["relu"] and z is not None      # z None: mask recomputed from y (forward without residual)
@@ -276,7 +350,13 @@ def bn_bwd_group(items, eval_mode):
         a.dres_accumulate = int(bool(it.get("dres_accumulate", False)))
         a.npix, a.C, a.partial, a.nchunks = npix, Cn, ptr(part), nch
         a.dy_absmax = ptr(it.get("dy_absmax"))
-    call("hrseg_bn_bwd_group", n, arr, int(eval_mode))
+    if sync is not None:
+        import torch.distributed as dist
+        call("hrseg_bn_bwd_group_phases", n, arr, 0, 1)
+        dist.all_reduce(pool, op=dist.ReduceOp.SUM, group=sync)
+        call("hrseg_bn_bwd_group_phases", n, arr, 0, 6)
+    else:
+        call("hrseg_bn_bwd_group", n, arr, int(eval_mode))
     return [it["dz"] for it in items]
 
 
@@ -346,6 +426,37 @@ def nhwc_to_nchw(x):
     out = torch.empty((B, Cn, H, W), dtype=torch.float32, device=x.device)
     call("hrseg_nhwc_to_nchw", ptr(x), _ld(x), ptr(out), B, Cn, H, W)
     return out
+
+
+def concat_image_logits(x, z):
+    """NCHW image [B,Ci,H,W] + NCHW logits [B,C,H,W] -> NHWC [B,H,W,Ci+C] (the input of a logit-concatenated level pass)"""
+    x, z = _c(x.float()), _c(z.float())
+    B, Ci, H, W = x.shape
+    Cz = z.shape[1]
+    out = torch.empty((B, H, W, Ci + Cz), dtype=torch.float32, device=x.device)
+    call("hrseg_nchw_to_nhwc", ptr(x), ptr(out), Ci + Cz, B, Ci, H, W)
+    call("hrseg_nchw_to_nhwc", ptr(z), out.data_ptr() + 4 * Ci, Ci + Cz, B, Cz, H, W)
+    return out
+
+
+def nhwc_slice_to_nchw(g, c0):
+    """channels [c0:] of an NHWC tensor as a contiguous NCHW tensor"""
+    B, H, W, Cn = g.shape
+    assert g.is_contiguous()
+    out = torch.empty((B, Cn - c0, H, W), dtype=torch.float32, device=g.device)
+    call("hrseg_nhwc_to_nchw", g.data_ptr() + 4 * c0, Cn, ptr(out), B, Cn - c0, H, W)
+    return out
+
+
+def accumulate_flat(dst, src):
+    """dst += src for two contiguous fp32 tensors of the same size (the copy kernel's accumulate form)"""
+    n = dst.numel()
+    assert src.numel() == n and dst.is_contiguous() and src.is_contiguous()
+    if n % 4 == 0 and n > 0:
+        call("hrseg_copy", ptr(src), 4, ptr(dst), 4, 1, n // 4, 4)
+    else:
+        dst.add_(src)
+    return dst
 
 
 def encode_targets(label, on_lut, parent):
@@ -531,6 +642,25 @@ def consistency_bwd(p, pprev, g, scale, group_parent, group_size):
     call("hrseg_consistency_bwd", ptr(p), ptr(pprev), ptr(g), float(scale), ptr(dp), ptr(dpprev), B, Cn, pprev.shape[1],
          H * W, len(group_parent), _lib.int_array(group_parent), _lib.int_array(group_size))
     return dp, dpprev
+
+
+def group_kl_sums(z, pprev, group_parent, group_size):
+    """-> [ngroups] float64: sum over b, pixels and the group's children of Q (log Q + log size) (hrseg_group_kl)"""
+    z, pprev = _c(z), _c(pprev)
+    B, Cn, H, W = z.shape
+    out = zeros((len(group_parent),), torch.float64, z.device)
+    call("hrseg_group_kl", ptr(z), ptr(pprev), ptr(out), B, Cn, pprev.shape[1], H * W, len(group_parent),
+         _lib.int_array(group_parent), _lib.int_array(group_size))
+    return out
+
+
+def group_kl_bwd(z, pprev, g, scale, group_parent, group_size):
+    z, pprev = _c(z), _c(pprev)
+    B, Cn, H, W = z.shape
+    dz = torch.empty_like(z)
+    call("hrseg_group_kl_bwd", ptr(z), ptr(pprev), ptr(g), float(scale), ptr(dz), B, Cn, pprev.shape[1], H * W,
+         len(group_parent), _lib.int_array(group_parent), _lib.int_array(group_size))
+    return dz
 
 
 def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):

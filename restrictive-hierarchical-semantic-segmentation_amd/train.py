@@ -194,10 +194,14 @@ def _append_metrics(vec, accuracy, IoU, dice, precision, recall, clssMetrics, ho
 
 # ----------------------------------------------------------------------------- loss
 def get_loss(output_logits, targets, lossFuncts, levelLoss, level_weights=None, loss=0.0, lvlLossGrad=[],
-             cur_level=None, cur_epoch=None, pretrain_epoch=None, probs_per_level=None, model=None):
+             cur_level=None, cur_epoch=None, pretrain_epoch=None, probs_per_level=None, model=None, *, lambda_kl=None,
+             kl_probs=None):
     """reference train.py:111-152.  With this package's loss objects each level is ONE fused
     CE+Dice launch; ``levelLoss`` accumulates 0-dim device tensors (no .item() sync) that
-    behave like the reference's floats under ``+`` and ``/``."""
+    behave like the reference's floats under ``+`` and ``/``.
+    Extension (keyword-only, default off; the reference's get_loss has no such argument): ``lambda_kl`` adds
+    lambda_kl * grouped_conditional_kl per level L >= 1 (the stabiliser of Metrics/losses.py:180-210); ``kl_probs`` are
+    the parent probabilities it is gated with (default: ``probs_per_level``)."""
     total_levels = len(output_logits)
     if pretrain_epoch is not None:
         cur_level_cap = int(min(total_levels - 1, (cur_epoch // pretrain_epoch)))
@@ -210,8 +214,9 @@ def get_loss(output_logits, targets, lossFuncts, levelLoss, level_weights=None, 
         ce_fn, dice_fn = lossFuncts[L][0], lossFuncts[L][1]
         if isinstance(ce_fn, losses.CrossEntropyLoss) and isinstance(dice_fn, losses.SoftDiceLoss):
             res = losses.fused_ce_dice(output_logits[L], targets[L], level_weight)
-            # Dice is 0 with zero gradient when no item is valid == the reference skipping None
-            level = res[0] + res[1]
+            # Dice is 0 with zero gradient when no item is valid == the reference skipping None; under data
+            # parallelism its divisor is the global count of valid items (losses.global_batch_dice)
+            level = res[0] + losses.global_batch_dice(res)
             loss = loss + level
             levelLoss[L] = levelLoss[L] + level.detach()
         else:
@@ -226,6 +231,13 @@ def get_loss(output_logits, targets, lossFuncts, levelLoss, level_weights=None, 
     if (probs_per_level is not None) and (model is not None) and hasattr(model, "levels") and hasattr(model, "parent_of"):
         loss = loss + losses.hierarchical_consistency_loss(probs_per_level, model.levels, model.parent_of,
                                                            reduction="mean")
+    if lambda_kl and model is not None and hasattr(model, "child_groups"):
+        gate = kl_probs if kl_probs is not None else probs_per_level
+        for L in range(1, total_levels):
+            if gate is None or not model.child_groups[L - 1]:
+                continue
+            loss = loss + float(lambda_kl) * losses.grouped_conditional_kl(output_logits[L], gate[L - 1],
+                                                                          model.child_groups[L - 1], model.levels[L - 1])
     return loss, lvlLossGrad, levelLoss
 
 

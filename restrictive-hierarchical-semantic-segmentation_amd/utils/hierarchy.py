@@ -110,3 +110,48 @@ def _find(tree, name):
             if r is not None:
                 return r
     return None
+
+
+
+class TreeIndex:
+    """One breadth-first pass over the class tree, shared by everything that walks it (predictEval's level synthesis,
+    the target encoder): per node its depth, parent, direct children, leaf flag and the leaves below it.
+
+    order     node names breadth first (= target channel order)
+    levels    names per depth, in `order`
+    children  name -> direct children (insertion order; [] for leaves)
+    parent    name -> parent name (None at depth 0)
+    depth     name -> depth
+    leaves    name -> descendant leaves in depth-first order (a leaf maps to [itself])"""
+
+    def __init__(self, tree):
+        self.order, self.levels = [], []
+        self.children, self.parent, self.depth = {}, {}, {}
+        frontier = [(name, sub, None) for name, sub in tree.items()]
+        d = 0
+        while frontier:
+            self.levels.append([name for name, _, _ in frontier])
+            nxt = []
+            for name, sub, par in frontier:
+                self.order.append(name)
+                self.parent[name], self.depth[name] = par, d
+                kids = list(sub.keys()) if _is_branch(sub) else []
+                self.children[name] = kids
+                nxt.extend((k, sub[k], name) for k in kids)
+            frontier, d = nxt, d + 1
+        # leaves below every node: children are later in `order`, so one reverse sweep sees them first
+        self.leaves = {}
+        for name in reversed(self.order):
+            kids = self.children[name]
+            self.leaves[name] = [name] if not kids else [leaf for k in kids for leaf in self.leaves[k]]
+
+    def is_leaf(self, name):
+        return not self.children[name]
+
+    @property
+    def leaf_names(self):
+        return [n for n in self.order if not self.children[n]]
+
+    @property
+    def parent_names(self):
+        return [n for n in self.order if self.children[n]]

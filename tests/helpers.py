@@ -52,3 +52,54 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+# ---- convolution arithmetic modes of the parity tests -------------------------------------------------------------
+# "auto"    the default policy with the default routing thresholds (small cases: mostly the exact-fp32 kernels)
+# "f32"     exact-fp32 MFMA kernels everywhere
+# "fp16x2"  the split-precision kernels everywhere, routing thresholds lowered to 1 tile: wave-specialised single launches,
+#           block-synchronous halo-patch / pgroup launches, im2col kernels, nine-tap + tap-per-block weight gradients
+# "auto_ws" the default policy with the thresholds lowered: what the 620x620 headline runs (wave-specialised GROUP
+#           launches of the parallel branches, fp16x2 im2col kernels for 1x1 / stride-2 layers), at golden sizes
+CONV_MODES = ["auto", "f32", "fp16x2", "auto_ws"]
+
+
+class conv_mode:
+    """context manager: sets model.conv_dtype and the library's routing thresholds for `mode`, counts launches per
+    kernel family while active (self.counts after exit)"""
+
+    def __init__(self, model, mode):
+        self.model, self.mode, self.counts = model, mode, {}
+
+    def __enter__(self):
+        from hrseg_amd import _lib
+        self.model.conv_dtype = {"auto_ws": "auto"}.get(self.mode, self.mode)
+        if self.mode in ("fp16x2", "auto_ws"):
+            _lib.tune(sp_ws_min_tiles=1, sp_patch_min_tiles=1, auto_min_pixels=1)
+        _lib.launch_count(None, reset=True)
+        return self
+
+    def __exit__(self, *exc):
+        from hrseg_amd import _lib
+        for fam in ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group", "wgrad_sp",
+                    "wgrad_f32", "wgrad_f32_group", "wgrad9"):
+            self.counts[fam] = _lib.launch_count(fam, reset=True)
+        _lib.tune(sp_ws_min_tiles=0, sp_patch_min_tiles=0, auto_min_pixels=0)      # 0 = defaults
+        return False
+
+    def check_families(self, kind):
+        """the case really ran the kernels its mode names"""
+        c = self.counts
+        if self.mode == "f32":
+            assert c["ws"] + c["ws_group"] + c["patch_sp"] + c["sp_im2col"] + c["sp_pgroup"] + c["sp_group"] == 0, c
+            assert c["f32"] + c["f32_group"] > 0 and c["wgrad9"] + c["wgrad_sp"] == 0, c
+        elif self.mode == "fp16x2":
+            # (grouped weight gradients of 1x1 / stride-2 layers have one kernel family, the exact-fp32 one)
+            assert c["f32"] + c["f32_group"] + c["wgrad_f32"] == 0, c
+            assert c["ws"] > 0 and c["wgrad9"] > 0, c
+            if kind == "hrnet":
+                assert c["sp_im2col"] > 0 and c["wgrad_sp"] > 0, c
+        elif self.mode == "auto_ws":
+            assert c["ws"] + c["ws_group"] > 0 and c["wgrad9"] > 0, c
+            if kind == "hrnet":
+                assert c["ws_group"] > 0 and c["sp_im2col"] + c["sp_group"] > 0, c

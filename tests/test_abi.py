@@ -13,7 +13,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(hrseg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|long|size_t|const char\*)\s+(hrseg_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
         decls[m.group(2)] = [] if args == ["void"] else args
     return decls
@@ -33,7 +33,8 @@ def test_header_symbols_exported_and_prototypes_match():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
-        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune", "hrseg_conv_wgrad_workspace_bytes"):
+        if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune", "hrseg_conv_wgrad_workspace_bytes",
+                    "hrseg_launch_count"):
             continue
         protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
         assert name in protos, f"{name} has no ctypes prototype"
@@ -43,7 +44,7 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.abi_version() == _lib.ABI_VERSION == 7
     assert not any(n.startswith("hrseg_debug_") for n in decls), "experimental switches do not belong in the public header"
 
 

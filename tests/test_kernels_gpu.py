@@ -571,3 +571,53 @@ def test_batchnorm_batched_passes(ops, C, H, W, B, L, res):
     assert rel(bw["dgamma"], gr.grad) < 2e-5 and rel(bw["dbeta"], br.grad) < 2e-5
     if res:
         assert rel(nchw(bw["dres"]), torch.cat(dres_refs)) < 1e-6
+
+
+@pytest.mark.parametrize("tree_groups", [
+    ([("tooth", ["pulp", "dentin", "enamel", "composite"])], ["background", "upper", "lower", "tooth"]),
+    ([("a", ["c", "d"]), ("b", ["e", "f", "g"])], ["a", "b"]),
+])
+def test_grouped_conditional_kl_fwd_bwd(tree_groups):
+    """hrseg_group_kl / hrseg_group_kl_bwd (the opt-in stabiliser of the reference's Metrics/losses.py:180-210) against
+    the oracle twin's autograd; logits include near-saturated pixels (the clamp_min(1e-8) branch)"""
+    from oracle import losses as OL
+    from hrseg_amd.Metrics import losses as PL
+    groups, levels_prev = tree_groups
+    C = sum(len(ch) for _, ch in groups)
+    g = torch.Generator().manual_seed(C)
+    z = torch.randn(2, C, 33, 29, generator=g) * 3.0
+    z[0, 0, :4, :4] = 40.0                                   # saturated softmax
+    pp = torch.rand(2, len(levels_prev), 33, 29, generator=g)
+    zo = z.clone().requires_grad_(True)
+    lo = OL.grouped_conditional_kl(zo, pp, groups, levels_prev)
+    lo.backward()
+    zp = z.cuda().requires_grad_(True)
+    ppd = pp.cuda().requires_grad_(True)
+    lp = PL.grouped_conditional_kl(zp, ppd, groups, levels_prev)
+    assert abs(float(lp) - float(lo)) < 1e-5 * max(1.0, abs(float(lo)))
+    (3.0 * lp).backward()
+    assert float((zp.grad.cpu() / 3.0 - zo.grad).abs().max()) < 1e-5 * float(zo.grad.abs().max()) + 1e-9
+    assert ppd.grad is None                                   # constant log-bias inside a group: no gradient
+
+
+def test_get_loss_adds_the_kl_term_only_when_asked():
+    import argparse
+    from oracle import losses as OL
+    from hrseg_amd import train as PT
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd.utils.hierarchy import build_hierarchy_indices, child_groups
+    from tests.helpers import load_tree, level_weights_for
+    tree = load_tree("class_tree_tl.json")
+    levels, parent_of, children_of = build_hierarchy_indices(tree)
+    model = argparse.Namespace(levels=levels, parent_of=parent_of, child_groups=child_groups(levels, children_of))
+    g = torch.Generator().manual_seed(3)
+    logits = [torch.randn(2, 4, 16, 16, generator=g).cuda() for _ in range(2)]
+    lab = torch.randint(0, 4, (2, 16, 16), generator=g)
+    targets = [torch.nn.functional.one_hot(lab, 4).permute(0, 3, 1, 2).float().cuda() for _ in range(2)]
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=4)] for _ in range(2)]
+    w = level_weights_for("class_tree_tl.json", True)
+    probs = [torch.sigmoid(z) for z in logits]
+    base, _, _ = PT.get_loss(logits, targets, fns, [], w, 0.0, [], probs_per_level=probs, model=model)
+    with_kl, _, _ = PT.get_loss(logits, targets, fns, [], w, 0.0, [], probs_per_level=probs, model=model, lambda_kl=0.1)
+    want = 0.1 * float(OL.grouped_conditional_kl(logits[1].cpu(), probs[0].cpu(), model.child_groups[0], levels[0]))
+    assert abs(float(with_kl) - float(base) - want) < 1e-5

@@ -57,6 +57,23 @@ def _worker(rank, world, port):
         assert c.dtype == torch.int64 and torch.equal(c, want)
         m = metrics_from_confusion(c, child_classes=(L > 0))
         assert torch.allclose(m["iou"], metrics_from_confusion(want, child_classes=(L > 0))["iou"])
+    # Dice under data parallelism: the divisor is the GLOBAL number of valid items (reference losses.py:64-66 on the
+    # gathered batch).  Rank 0: two items, both valid; rank 1: two items, one all-ignored at this level.
+    from hrseg_amd.Metrics.losses import global_batch_dice
+    item_dice = [[0.30, 0.50], [0.80]][rank]                      # per-item Dice values of the rank's valid items
+    local = torch.tensor(item_dice, dtype=torch.float64, requires_grad=True)
+    res = [torch.zeros(()), local.mean().float(), torch.tensor(float(len(item_dice)))]
+    term = global_batch_dice(res)
+    gathered = (0.30 + 0.50 + 0.80) / 3.0
+    avg = term.detach().clone().double().reshape(1)
+    dist.all_reduce(avg)
+    assert abs(float(avg) / world - gathered) < 1e-6, (float(avg) / world, gathered)       # mean over ranks = gathered Dice
+    term.backward()
+    # gradient averaged over the ranks: d(gathered)/d(item) = 1/3 for every valid item
+    assert torch.allclose(local.grad / world, torch.full_like(local, 1.0 / 3.0), atol=1e-6), local.grad
+    # no valid item anywhere: the term is zero, not NaN
+    z = global_batch_dice([torch.zeros(()), torch.zeros((), requires_grad=True) * 1.0, torch.tensor(0.0)])
+    assert float(z) == 0.0
     dist.destroy_process_group()
 
 

@@ -85,3 +85,72 @@ def test_validation_loop_matches_the_oracle_eval_pass(name):
     assert len(level_loss) == len(want_levels)
     for a, b in zip(level_loss, want_levels):
         assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (level_loss, want_levels)
+
+
+@pytest.mark.parametrize("kind,hier", [("unet", False), ("unet", True), ("hrnet", False)])
+def test_predict_loop_matches_the_oracle(kind, hier, tmp_path):
+    """predictEval.predict_loop (the per-fold body of the reference's predict(), predictEval.py:305-573): eval forward,
+    prediction prep (flat models: parents synthesised from the leaves; hierarchical: one-hot per level), -1 masking,
+    get_metrics, the PNG dump of each batch's first image and metrics.csv -- per-class metrics against the oracle's
+    eval pass + the oracle twins of get_parent_masks / combine_levels / level_metrics"""
+    import csv
+    from PIL import Image
+    from oracle import metrics as OM
+    from oracle import models as OMod
+    from oracle import predict_eval as OPE
+    from oracle.train_step import split_levels
+    from hrseg_amd import predictEval as PE
+    from hrseg_amd.Metrics import performance_metrics as PP
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.utils import synth
+    from hrseg_amd.utils.hierarchy import get_classes
+    tree = load_tree("class_tree_tl.json")
+    size, batch = 64, 2
+    nc_full = get_classes(tree, full=True)
+    xn, tn = synth.synthetic_batch(tree, 2 * batch, size, seed=41, hierarchical=hier, blob=6)
+    batches = [(torch.from_numpy(xn[i:i + batch]), torch.from_numpy(tn[i:i + batch])) for i in (0, batch)]
+    args = argparse.Namespace(model_type=1 if hier else 0, model_select=0 if kind == "unet" else 1,
+                              num_classes=nc_full if hier else [sum(get_classes(tree, full=False))],
+                              num_classes_full=nc_full, batch_size=batch)
+    om = build_model(OMod, kind, hier, tree, size)
+    om.eval()
+    pm = build_model(PM, kind, hier, tree, size).cuda()
+    mets = [PP.Accuracy(), PP.Jaccardindex(), PP.DiceScore(), PP.Precision(), PP.Recall()]
+    out = PE.predict_loop(pm, torch.device("cuda"), batches, args, tree, *mets, save_dir=str(tmp_path / "pred"))
+    # oracle
+    ch = OPE.children_map(tree)
+    leaves = [n for n in OPE.bfs_order(tree) if not ch[n]]
+    parents = [n for n in OPE.bfs_order(tree) if ch[n]]
+    per_batch, first_planes = [], []
+    for x, t in batches:
+        with torch.no_grad():
+            _, z = om(x, type=args.model_type) if kind == "unet" else om(x)
+        if hier:
+            targets = [a.numpy() for a in split_levels(t, nc_full)]
+            preds = [OM.one_hot_predictions(zz.numpy()) for zz in z]
+        else:
+            oh = OM.one_hot_predictions(z.numpy())
+            px, py, _ = OPE.get_parent_masks(oh, t.numpy(), tree, {n: i for i, n in enumerate(leaves)})
+            preds = OPE.combine_levels(oh, px, tree, leaves, parents)
+            targets = OPE.combine_levels(t.numpy(), py, tree, leaves, parents)
+        preds = [np.where(tt == -1, 0.0, p).astype(np.float32) for p, tt in zip(preds, targets)]
+        ev = [np.where(tt == -1, 0.0, tt).astype(np.float32) for tt in targets]
+        per_batch.append({k: np.concatenate([OM.level_metrics(p, e, child_classes=(L > 0))[k]
+                                             for L, (p, e) in enumerate(zip(preds, ev))]) for k in OM.METRIC_NAMES})
+        first_planes.append(np.concatenate([p[0] for p in preds], 0))
+    for c in range(sum(nc_full)):
+        for k in OM.METRIC_NAMES:
+            want = float(np.mean([b[k][c] for b in per_batch]))
+            got = float(np.mean(out["class_metrics"][c][k]))
+            assert abs(got - want) < 2e-3, (c, k, got, want)
+    assert abs(out["iou"] - float(np.mean([b["iou"].mean() for b in per_batch]))) < 2e-3
+    # the PNG dump: first image of every batch, one 0/255 file per class; a handful of arg-max ties may flip
+    for i, planes in enumerate(first_planes):
+        for c in range(sum(nc_full)):
+            img = np.array(Image.open(tmp_path / "pred" / str(c) / f"{i:05d}.png"))
+            assert img.shape == (size, size) and set(np.unique(img)) <= {0, 255}
+            assert np.mean((img > 0) != (planes[c] > 0.5)) < 2e-3, (i, c)
+    rows = list(csv.reader(open(tmp_path / "pred" / "metrics.csv")))
+    assert rows[0] == ["Type", "Class", "Accuracy", "IoU", "Dice", "Precision", "Recall"]
+    assert rows[1][:2] == ["Average", "All"] and abs(float(rows[1][3]) - out["iou"]) < 1e-6
+    assert len(rows) == 2 + sum(nc_full) and rows[2][:2] == ["Class", "0"]

@@ -174,3 +174,66 @@ def test_scratch_ring_wraps_and_small_scratch_falls_back():
         torch.cuda.synchronize()
         _lib._scratch = None            # ops re-attaches the default buffer at the next convolution
         _lib.ensure_scratch(x.device)
+
+
+@pytest.mark.parametrize("mb", [64, 48])
+def test_group_images_never_wrap_inside_a_group(mb):
+    """the four-branch group (86 KB + 344 KB + 1.3 MB + 5.3 MB of weight images) with a small scratch buffer: with
+    8 MiB regions (64 MiB) the group fits once and every later group wraps BEFORE its first image; with 6 MiB regions
+    (48 MiB) the group does not fit and the launch takes its other kernels.  Either way forward and data gradient must
+    equal the exact-fp32 kernels' results over several rounds with changing weights (a wrap inside a group would
+    overwrite an earlier image of the same launch: the round-2 defect)."""
+    from hrseg_amd import _lib, ops
+    auto = _lib.CONV_PRECISION["auto"]
+    chans, xs, _ = _branches(8, seed=13)
+    g = torch.Generator().manual_seed(77)
+    rounds = [[(torch.randn(c, 9, c, generator=g) / (9 * c) ** 0.5).cuda() for c in chans] for _ in range(4)]
+    dys = [torch.randn_like(x) for x in xs]
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    try:
+        small = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+        _lib.call_raw("hrseg_set_scratch", small.data_ptr(), small.numel())
+        _lib.launch_count(None, reset=True)
+        for ws in rounds:
+            ys = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=auto)
+            wts = [ops.weight_transpose(w, c, 9, c) for w, c in zip(ws, chans)]
+            dxs = ops.conv_dgrad_group(dys, wts, [x.shape for x in xs], 3, 1, [None] * 4, [False] * 4, prec=auto, gmaxs=gms)
+            for i in range(4):
+                assert _rel(ys[i], ops.conv_fwd(xs[i], ws[i], None, 3, 1, prec=0)) < TOL, i
+                assert _rel(dxs[i], ops.conv_dgrad(dys[i], wts[i], xs[i].shape, 3, 1, prec=0)) < TOL, i
+        n_group = _lib.launch_count("ws_group")
+        assert (n_group == 8) if mb == 64 else (n_group == 0), n_group
+    finally:
+        torch.cuda.synchronize()
+        _lib._scratch = None
+        _lib.ensure_scratch(xs[0].device)
+
+
+def test_fp16x2_out_of_range_activations_are_loud_and_guarded():
+    """fp16x2 takes its activation operand unscaled: far beyond the fp16 range the result must be Inf / NaN (never a
+    silently saturated finite value), NaN inputs must propagate, and in deterministic mode ops.py range-checks the
+    operand (hrseg_absmax) and runs the exact-fp32 kernels instead"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 40, 48, 96, generator=g).cuda()
+    w = (torch.randn(96, 9, 96, generator=g) / 30).cuda()
+    x_big = x.clone()
+    x_big[0, 7, 9, 5] = 3.0e5                              # > 2 * 65504: not representable by the two fp16 pieces
+    want = ops.conv_fwd(x_big, w, None, 3, 1, prec=0)
+    got = ops.conv_fwd(x_big, w, None, 3, 1, prec=pr)
+    assert not bool(torch.isfinite(got).all()), "an out-of-range activation must not give a finite (saturated) result"
+    x_nan = x.clone()
+    x_nan[1, 3, 3, 0] = float("nan")
+    assert bool(torch.isnan(ops.conv_fwd(x_nan, w, None, 3, 1, prec=pr)[1, 3, 3]).all()), "NaN must propagate"
+    assert float(ops.absmax(x_nan)) == float("inf") and abs(float(ops.absmax(x)) - float(x.abs().max())) == 0.0
+    _lib.set_deterministic(True)
+    try:
+        before, _ = ops.range_fallbacks, _lib.launch_count(None, reset=True)
+        got = ops.conv_fwd(x_big, w, None, 3, 1, prec=pr)
+        assert ops.range_fallbacks == before + 1 and _lib.launch_count("f32") == 1 and _lib.launch_count("ws") == 0
+        assert torch.equal(got, want)
+        ok = ops.conv_fwd(x, w, None, 3, 1, prec=pr)            # in range: stays on the fp16x2 kernels
+        assert ops.range_fallbacks == before + 1 and _rel(ok, ops.conv_fwd(x, w, None, 3, 1, prec=0)) < TOL
+    finally:
+        _lib.set_deterministic(False)
