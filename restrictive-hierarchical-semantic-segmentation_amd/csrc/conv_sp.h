@@ -1500,6 +1500,160 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
           out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
 }
 
+// ---- role-split form of the nine-tap weight gradient (fp16x2).  In wgrad9_sp_body every wave alternates ~550 staging
+// instructions (loads, splits, ds_writes) with its 162 MFMAs per tile, and 1.5 waves per SIMD do not hide that (MFMA-busy
+// 0.39).  Here a 384-thread block splits the roles as the wave-specialised forward body does: waves 0-2 (kernel rows) are
+// CONSUMERS and run only the MFMA section on one of TWO image buffers; waves 3-5 are PRODUCERS and stage the next tile into
+// the other buffer (its global loads were issued a whole tile earlier).  ONE barrier per tile: at barrier t the producers
+// have finished storing tile t and the consumers have finished computing tile t-1, so after it the consumers read buffer
+// t&1 while the producers overwrite buffer (t+1)&1.  Both roles pass the same number of barriers.  Per-accumulator product
+// order is that of wgrad9_sp_body: results are bit-identical (tests/test_ws_gpu.py).
+template <int NS, int TNK>
+__device__ __forceinline__ void wgrad9_ws_body(const Wgrad9Args& p, unsigned char* lds, const int pair, const int chunk) {
+  using L = SpWgrad9Lds<NS, TNK>;
+  constexpr int S = L::S, PIECE = L::PIECE, XBASE = L::DYPIX * S, BUF = L::BYTES;
+  constexpr int GPP = TNK * 4;
+  constexpr int NT = 192, PR = NT / GPP;
+  constexpr int DY_LOADS = (L::DYPIX + PR - 1) / PR, X_LOADS = (L::XPIX + PR - 1) / PR, LOADS = DY_LOADS + X_LOADS;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool consumer = wave < 3;
+  const int lane = threadIdx.x & 63;
+  const int nkt = p.Cin / (16 * TNK);
+  const int ct = pair / nkt, kt = pair - ct * nkt;
+  const int n0 = ct * 16 * TNK, k0 = kt * 16 * TNK;
+  const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
+  float dyscale, dyinv;
+  sp_pow2_scale(p.dymax, dyscale, dyinv);
+
+  if (!consumer) {
+    const int tid = threadIdx.x - 192;
+    f32x4 rg[LOADS];
+    const int pix0 = tid / GPP, gq = tid - pix0 * GPP;
+    const bool swork = pix0 < PR;
+    auto tile_load = [&](int t) {
+      const int tx = t % p.tiles_x;
+      int r = t / p.tiles_x;
+      const int ty = r % p.tiles_y, b = r / p.tiles_y;
+      const int y0 = ty * 4, x0 = tx * 16;
+      const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
+#pragma unroll
+      for (int i = 0; i < DY_LOADS; ++i) {
+        const int pix = pix0 + PR * i;
+        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
+        const bool ok = swork & (pix < L::DYPIX) & (iy < p.H) & (ix < p.W);
+        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+        rg[i] = buf_load4(rdy, off, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < X_LOADS; ++i) {
+        const int pix = pix0 + PR * i;
+        const int py = (pix * 3641) >> 16, px = pix - py * 18;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = swork & (pix < L::XPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+        rg[DY_LOADS + i] = buf_load4(rx, off, 0);
+      }
+    };
+    auto tile_store = [&](unsigned char* base) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        u32x2 pc[sp_np(NS)];
+        sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
+        const int pix = (i < DY_LOADS) ? pix0 + PR * i : L::DYPIX + pix0 + PR * (i - DY_LOADS);
+        const int o = pix * S + gq * 8;
+        if (swork && (i < DY_LOADS ? pix < L::DYPIX : pix < L::DYPIX + L::XPIX)) {
+#pragma unroll
+          for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(base + q * PIECE + o) = pc[q];
+        }
+      }
+    };
+    if (t_lo < t_hi) {
+      tile_load(t_lo);
+      tile_store(lds);
+      if (t_lo + 1 < t_hi) tile_load(t_lo + 1);
+    }
+    __syncthreads();                                   // barrier t_lo: the first tile is staged
+    for (int t = t_lo; t < t_hi; ++t) {
+      if (t + 1 < t_hi) {
+        tile_store(lds + ((t + 1 - t_lo) & 1) * BUF);  // (the consumers left this buffer before the last barrier)
+        if (t + 2 < t_hi) tile_load(t + 2);            // in flight for a whole tile of MFMAs
+      }
+      __syncthreads();                                 // barrier t+1
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------- consumers: wave = kernel row
+  const int kh = wave;
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 acc[3][TNK][TNK];
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int n = 0; n < TNK; ++n)
+#pragma unroll
+      for (int k = 0; k < TNK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lrow = li >> 2, lcol = (li & 3) * 8;
+  const int dy_lane = (4 * g + lrow) * S + lcol;
+  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * S + lcol;
+  for (int t = t_lo; t < t_hi; ++t) {
+    __syncthreads();                                   // barrier t: tile t is staged
+    const unsigned char* img = lds + ((t - t_lo) & 1) * BUF;
+    bf16x8 afr[TNK][sp_np(NS)], bfr[TNK][sp_np(NS)];
+    auto read_a = [&](int ks) {
+#pragma unroll
+      for (int n = 0; n < TNK; ++n)
+#pragma unroll
+        for (int pc = 0; pc < sp_np(NS); ++pc) {
+          const s16x4 v0 = sp_tr_read(img + pc * PIECE + dy_lane + (2 * ks) * 16 * S + n * 32);
+          const s16x4 v1 = sp_tr_read(img + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * S + n * 32);
+          afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+        }
+    };
+    auto read_b = [&](int grp, int k) {
+      const int ks = grp / 3, kw = grp % 3;
+#pragma unroll
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
+        const s16x4 v0 = sp_tr_read(img + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
+        const s16x4 v1 = sp_tr_read(img + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
+        bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+    };
+    read_a(0);
+#pragma unroll
+    for (int k = 0; k < TNK; ++k) read_b(0, k);
+#pragma unroll
+    for (int grp = 0; grp < 6; ++grp) {
+      const int kw = grp % 3;
+      if (grp == 3) read_a(1);
+#pragma unroll
+      for (int k = 0; k < TNK; ++k) {
+#pragma unroll
+        for (int pr = 0; pr < sp_nprod(NS); ++pr)
+#pragma unroll
+          for (int n = 0; n < TNK; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + 1 < 6) read_b(grp + 1, k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();                                     // the producers' last barrier (t_hi)
+  float* out = p.ws + (size_t)chunk * p.Cout * 9 * p.Cin;
+  const int row9 = 9 * p.Cin;
+  const int obase = ((n0 + 4 * g) * 9 + kh * 3) * p.Cin + k0 + li;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int n = 0; n < TNK; ++n)
+#pragma unroll
+      for (int k = 0; k < TNK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
+}
+
 #define WG9_MAXG 8
 struct Wgrad9Group {
   int n;
@@ -1526,6 +1680,30 @@ template <int NS>
 __global__ __launch_bounds__(192) void wgrad9_sp_group_kernel4(Wgrad9Group grp) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9Lds<NS, 4>::BYTES];
   wgrad9_sp_group_entry<NS, 4>(grp, lds);
+}
+
+// role-split kernels (fp16x2 only): 384 threads = three consumer + three producer waves, two image buffers.
+// Blocks are remapped so that each XCD owns a contiguous range of the work list: the tile pairs of one pixel chunk (which
+// re-read the same dy / x tiles) then share one L2.
+template <int NS, int TNK>
+__device__ __forceinline__ void wgrad9_ws_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int gi = 0;
+  while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
+  const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
+  const Wgrad9Args& p = grp.a[gi];
+  const int npairs = (p.Cout / (16 * TNK)) * (p.Cin / (16 * TNK));
+  wgrad9_ws_body<NS, TNK>(p, lds, local % npairs, local / npairs);
+}
+template <int NS>
+__global__ __launch_bounds__(384) void wgrad9_ws_group_kernel3(Wgrad9Group grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SpWgrad9Lds<NS, 3>::BYTES];
+  wgrad9_ws_group_entry<NS, 3>(grp, lds);
+}
+template <int NS>
+__global__ __launch_bounds__(384) void wgrad9_ws_group_kernel4(Wgrad9Group grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SpWgrad9Lds<NS, 4>::BYTES];
+  wgrad9_ws_group_entry<NS, 4>(grp, lds);
 }
 
 // dW[i] += sum over chunks (in chunk order) of ws[chunk][i]; n4 = elements / 4 per problem

@@ -16,7 +16,18 @@ int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, i
   return ns == 4 ? launch_wgrad_sp<4>(a, tn, tk, gx, tiles, st) : ns == 3 ? launch_wgrad_sp<3>(a, tn, tk, gx, tiles, st)
        : ns == 2 ? launch_wgrad_sp<2>(a, tn, tk, gx, tiles, st) : launch_wgrad_sp<1>(a, tn, tk, gx, tiles, st);
 }
-int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st) {
+int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st, int ws) {
+  // role-split form (three consumer + three producer waves).  48-channel tiles: 162 registers, two blocks per CU.  The
+  // 64-channel tiling keeps 192 accumulator registers per consumer wave: with six waves per block that spills (a block of
+  // six waves caps a wave at 256 registers), so it stays on the block-synchronous kernel unless wgrad9_ws = 2 forces it.
+  if (ns == 4 && ((ws && tnk == 3) || ws == 2)) {
+    if (tnk == 3) hipLaunchKernelGGL((wgrad9_ws_group_kernel3<4>), dim3(nblocks), dim3(384), 0, st, g);
+    else hipLaunchKernelGGL((wgrad9_ws_group_kernel4<4>), dim3(nblocks), dim3(384), 0, st, g);
+    HRSEG_LAUNCH_CHECK("wgrad9_ws");
+    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
+    HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+    return 0;
+  }
 #define W9(NS_) if (ns == NS_) { \
     if (tnk == 3) hipLaunchKernelGGL((wgrad9_sp_group_kernel3<NS_>), dim3(nblocks), dim3(192), 0, st, g); \
     else hipLaunchKernelGGL((wgrad9_sp_group_kernel4<NS_>), dim3(nblocks), dim3(192), 0, st, g); }

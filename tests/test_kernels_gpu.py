@@ -621,3 +621,32 @@ def test_get_loss_adds_the_kl_term_only_when_asked():
     with_kl, _, _ = PT.get_loss(logits, targets, fns, [], w, 0.0, [], probs_per_level=probs, model=model, lambda_kl=0.1)
     want = 0.1 * float(OL.grouped_conditional_kl(logits[1].cpu(), probs[0].cpu(), model.child_groups[0], levels[0]))
     assert abs(float(with_kl) - float(base) - want) < 1e-5
+
+
+@pytest.mark.parametrize("cin,stride,bias", [(7, 1, True), (7, 2, False), (5, 2, False), (3, 1, True)])
+def test_first_layer_direct_conv_kernels(cin, stride, bias):
+    """the direct (VALU) kernels of the first layer for Cin <= 8 -- image + previous level's logits with logit-concatenated
+    re-encoding -- forward, weight gradient and the data gradient (which reads the FORWARD weight layout) vs torch"""
+    import torch.nn.functional as F
+    from hrseg_amd import ops
+    g = torch.Generator().manual_seed(cin * 10 + stride)
+    B, H, W, cout = 3, 37, 45, 64
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, b, stride=stride, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()                  # [Cout][3][3][Cin]
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    yd = ops.conv_fwd(xd, wd.reshape(cout, 9, cin), b.cuda() if bias else None, 3, stride)
+    assert float((yd.permute(0, 3, 1, 2).cpu() - y.detach()).abs().max()) < 1e-5 * float(y.abs().max())
+    dw = torch.zeros_like(wd)
+    ops.conv_wgrad(xd, dyd, dw, 3, stride)
+    assert float((dw.permute(0, 3, 1, 2).cpu() - wr.grad).abs().max()) < 2e-5 * float(wr.grad.abs().max())
+    dx = ops.conv_dgrad(dyd, wd.reshape(cout, 9, cin), xd.shape, 3, stride)
+    assert float((dx.permute(0, 3, 1, 2).cpu() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
+    ops.conv_dgrad(dyd, wd.reshape(cout, 9, cin), xd.shape, 3, stride, out=dx, accumulate=True)
+    assert float((dx.permute(0, 3, 1, 2).cpu() - 2 * xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())

@@ -237,3 +237,36 @@ def test_fp16x2_out_of_range_activations_are_loud_and_guarded():
         assert ops.range_fallbacks == before + 1 and _rel(ok, ops.conv_fwd(x, w, None, 3, 1, prec=0)) < TOL
     finally:
         _lib.set_deterministic(False)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4])
+def test_role_split_wgrad9_bit_identical_to_block_synchronous(n):
+    """the role-split nine-tap weight gradient (three consumer + three producer waves, two image buffers, one barrier per
+    tile) adds the same products in the same order as the block-synchronous body: identical bits, for one problem and for
+    the grouped branch launches, including ragged image edges and accumulation into an existing gradient"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(40 + n)
+    chans, sizes = [48, 96, 192, 384][:n], [(61, 83), (31, 42), (16, 21), (8, 11)][:n]
+    xs = [torch.randn(5, h, w, c, generator=g).cuda() for c, (h, w) in zip(chans, sizes)]
+    dys = [(torch.randn(5, h, w, c, generator=g) * 1e-3).cuda() for c, (h, w) in zip(chans, sizes)]
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    base = [torch.randn(c, 9, c, generator=g).cuda() for c in chans]
+    outs = []
+    try:
+        for ws in (1, 0):
+            _lib.tune(wgrad9_ws=ws)
+            dws = [b.clone() for b in base]
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
+            assert _lib.launch_count("wgrad9") == 1
+            outs.append(dws)
+    finally:
+        _lib.tune(wgrad9_ws=1)
+    for a, b, x, dy, b0, c in zip(outs[0], outs[1], xs, dys, base, chans):
+        assert torch.equal(a, b), "role-split and block-synchronous weight gradients differ"
+        xr = x.permute(0, 3, 1, 2).cpu().requires_grad_(False)
+        wr = torch.zeros(c, c, 3, 3, requires_grad=True)
+        F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
+        got = (a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu()
+        assert _rel(got, wr.grad) < 4e-5
