@@ -654,7 +654,8 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
 // --------------------------------------------------------------------------- nine-tap weight gradient (workspace + ordered reduce)
 static int g_wg9_blocks = 0;           // hrseg_tune "wgrad9_blocks": target blocks per problem (0 = 256)
 static int g_wg9 = 1;                  // hrseg_tune "wgrad9": 0 = never use the nine-tap kernel
-static int g_wg9_ws = 1;               // hrseg_tune "wgrad9_ws": 0 = the block-synchronous nine-tap body
+static int g_wg9_ws = 0;               // hrseg_tune "wgrad9_ws": 1 = the role-split nine-tap body (measured slower)
+static int g_wg9_xcd = 0;              // hrseg_tune "wgrad9_xcd": 1 = XCD-contiguous block order in the nine-tap kernels
 // tiles per side of the dW tile (3: channels multiple of 48, 4: multiple of 64), 0 = not a nine-tap case
 static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   if (!g_wg9 || s.ksize != 3 || s.stride != 1 || sp_pieces(s.precision) == 0) return 0;
@@ -696,6 +697,7 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
   Wgrad9Group g;
   Wgrad9Reduce r;
   g.n = r.n = n;
+  g.xcd = g_wg9_xcd;
   int end = 0, rend = 0;
   for (int i = 0; i < n; ++i) {
     Wgrad9Args& a = g.a[i];
@@ -1125,7 +1127,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

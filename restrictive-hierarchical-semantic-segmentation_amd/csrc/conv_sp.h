@@ -1657,14 +1657,16 @@ __device__ __forceinline__ void wgrad9_ws_body(const Wgrad9Args& p, unsigned cha
 #define WG9_MAXG 8
 struct Wgrad9Group {
   int n;
+  int xcd;                 // 1: blocks are remapped so that each XCD owns a contiguous range of the work list
   int blk_end[WG9_MAXG];
   Wgrad9Args a[WG9_MAXG];
 };
 template <int NS, int TNK>
 __device__ __forceinline__ void wgrad9_sp_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
+  const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int gi = 0;
-  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
-  const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
+  while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
+  const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
   const Wgrad9Args& p = grp.a[gi];
   const int npairs = (p.Cout / (16 * TNK)) * (p.Cin / (16 * TNK));
   wgrad9_sp_body<NS, TNK>(p, lds, local % npairs, local / npairs);     // the tile pairs of one chunk are neighbours: same pixels
@@ -1687,7 +1689,7 @@ __global__ __launch_bounds__(192) void wgrad9_sp_group_kernel4(Wgrad9Group grp) 
 // re-read the same dy / x tiles) then share one L2.
 template <int NS, int TNK>
 __device__ __forceinline__ void wgrad9_ws_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int gi = 0;
   while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
   const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);

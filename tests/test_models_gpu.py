@@ -653,6 +653,7 @@ def test_concat_prev_logits_against_the_oracle(kind, size):
         return synth.fill_state_dict(m)
 
     om, pm = make(OM), make(PM).cuda()
+    pm.conv_dtype = "f32"
     assert [n for n, _ in om.named_parameters()] == [n for n, _ in pm.named_parameters()]
     assert any(n.startswith("cond_stems.0.") for n, _ in pm.named_parameters())
     xn, tn = synth.synthetic_batch(tree, 2, size, seed=31, hierarchical=True, blob=4)
@@ -662,7 +663,9 @@ def test_concat_prev_logits_against_the_oracle(kind, size):
     _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
     lo = lp = 0.0
     for L, (a, b) in enumerate(zip(zo, zp)):
-        assert rel_err(b.detach().cpu().numpy(), a.detach().numpy()) < TOL, f"train logits {L}"
+        # level L >= 1 re-encodes level L-1's logits: their (in-tolerance) difference from the oracle's is an INPUT
+        # perturbation of this pass on top of the pass's own rounding
+        assert rel_err(b.detach().cpu().numpy(), a.detach().numpy()) < (TOL if L == 0 else 3 * TOL), f"train logits {L}"
         t = target[:, 4 * L:4 * L + 4]
         lo = lo + OL.cross_entropy_loss(a, t, logits_input=True, class_weight=weights[L]) + \
             OL.soft_dice_loss(a, t, logits_input=True, class_weight=weights[L])
@@ -673,13 +676,27 @@ def test_concat_prev_logits_against_the_oracle(kind, size):
     lp.backward()
     og = dict(om.named_parameters())
     head0 = "heads.0.conv.weight" if kind == "unet" else "classifiers.0.weight"
+    # the first convolution sits behind every BN / ReLU of the net, where fp32 evaluations differ from each other at the
+    # percent level (ReLU flips; tests/diagnostics/grad_noise.py).  The yardstick is therefore an fp64 evaluation of the
+    # oracle: the product must be as close to it as the fp32 oracle is (x3), or within 5e-2 outright.
+    o64 = make(OM).double()
+    o64.train()
+    _, z64 = o64(x.double(), type=1) if kind == "unet" else o64(x.double())
+    l64 = 0.0
+    for L, a in enumerate(z64):
+        t = target[:, 4 * L:4 * L + 4].double()
+        l64 = l64 + OL.cross_entropy_loss(a, t, logits_input=True, class_weight=weights[L]) + \
+            OL.soft_dice_loss(a, t, logits_input=True, class_weight=weights[L])
+    l64.backward()
+    g64 = {n: p.grad for n, p in o64.named_parameters()}
     for n, p in pm.named_parameters():
-        if n.startswith("cond_stems.") or n == head0:
-            ref = og[n].grad
-            # (the first convolution sits behind every BN / ReLU of the net: fp32 evaluations differ by ~1e-2 there,
-            # tests/diagnostics/grad_noise.py; level 0's head receives part of its gradient through that path)
-            assert float((p.grad.cpu() - ref).abs().max()) < 5e-2 * float(ref.abs().max()) + 1e-7, n
-            assert float(ref.abs().max()) > 0
+        if n.startswith("cond_stems."):
+            ref = g64[n]
+            scale = float(ref.abs().max())
+            e_prod = float((p.grad.cpu().double() - ref).abs().max()) / scale
+            e_orc = float((og[n].grad.double() - ref).abs().max()) / scale
+            print(f"{n}: product vs fp64 {e_prod:.3e}, fp32 oracle vs fp64 {e_orc:.3e}")
+            assert scale > 0 and e_prod < max(5e-2, 3 * e_orc), (n, e_prod, e_orc)
     # the gradient that exists only because of the concatenation: the oracle with level 1's input DETACHED from the logits
     # of level 0 gives a different gradient for level 0's head; the product must sit with the full one
     om2 = make(OM)
@@ -701,16 +718,18 @@ def test_concat_prev_logits_against_the_oracle(kind, size):
         ld = ld + OL.cross_entropy_loss(a, t, logits_input=True, class_weight=weights[L]) + \
             OL.soft_dice_loss(a, t, logits_input=True, class_weight=weights[L])
     ld.backward()
-    g_full, g_det = og[head0].grad, dict(om2.named_parameters())[head0].grad
+    g_full, g_det = g64[head0].float(), dict(om2.named_parameters())[head0].grad
     g_prod = dict(pm.named_parameters())[head0].grad.cpu()
     gap = float((g_full - g_det).abs().max())
-    assert gap > 0 and float((g_prod - g_full).abs().max()) < 0.3 * gap, (gap, float((g_prod - g_full).abs().max()))
+    err = float((g_prod - g_full).abs().max())
+    print(f"head-0 gradient: |full - detached| = {gap:.3e}, |product - full| = {err:.3e}, max |full| = {float(g_full.abs().max()):.3e}")
+    assert gap > 0 and err < 0.3 * gap, (gap, err)
     om.eval(), pm.eval()
     with torch.no_grad():
         _, zo = om(x, type=1) if kind == "unet" else om(x)
         _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
     for L, (a, b) in enumerate(zip(zo, zp)):
-        assert rel_err(b.cpu().numpy(), a.numpy()) < TOL, f"eval logits {L}"
+        assert rel_err(b.cpu().numpy(), a.numpy()) < (TOL if L == 0 else 3 * TOL), f"eval logits {L}"
     pm.train()
     pm.dedup_passes = True
     with pytest.raises(RuntimeError):
