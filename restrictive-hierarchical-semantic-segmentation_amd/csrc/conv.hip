@@ -32,9 +32,9 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
@@ -360,6 +360,22 @@ static int launch_patch_sp(int ns, const IgemmArgs& a_in, int wtn, int cs, hipSt
   return launch_patch_sp_kernel(ns, a, wtn, cs, flip, blocks, ntotal, st);
 }
 
+// wide-tile im2col body (conv_sp.h: igemm_spw_body): channel tile in 16-channel units, 0 = not a case for it.
+// At least 96 output channels, a tile count that fills the chip (128-pixel tiles), and room in the scratch ring.
+static int g_sp_wide = 1;               // hrseg_tune "sp_wide": 0 = never use the wide-tile body
+static int g_spw_min_blocks = 256;      // hrseg_tune "sp_wide_min_blocks"
+static int spw_wtn(const IgemmArgs& a) {
+  if (!g_sp_wide || !scratch_usable() || a.K % 16 || a.M < 128) return 0;
+  const int wtn = (a.N % 240 == 0) ? 15 : (a.N % 192 == 0) ? 12 : (a.N % 128 == 0) ? 8 : (a.N % 96 == 0) ? 6 : 0;
+  if (!wtn) return 0;
+  if ((long)ceil_div(a.M, 128) * (a.N / (16 * wtn)) < g_spw_min_blocks) return 0;
+  // the body walks its slabs six at a time (register sets and LDS buffers are compile-time): short reductions would
+  // multiply zeros for most of a trip -- they stay on the narrow body (hrseg_tune sp_wide = 2 lifts the rule: tests)
+  const int nslabs = (a.ntaps * (a.K / 16) + 1) / 2, padded = (nslabs + 5) / 6 * 6;
+  if (g_sp_wide < 2 && (padded - nslabs) * 10 > nslabs) return 0;
+  return wtn;
+}
+
 static int launch_sp(int ns, const IgemmArgs& a, const SpPlan& pl, hipStream_t st) {
   if (launch_sp_kernel(ns, a, pl, st) == 0) { ++g_cnt[CNT_SP_IM2COL]; return 0; }
   hrseg_set_error("igemm_sp: no kernel for plan wtm=%d wtn=%d", pl.wtm, pl.wtn);
@@ -404,6 +420,17 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
     if (const int cs = patch_cs(a, pl.wtn)) {
       const int rc = launch_patch_sp(ns, a, pl.wtn, cs, st);
       if (rc == 0) return 0;
+    }
+    if (ns == 4 && !g_sp_wtn) {
+      // wide channel tiles + pre-split weights (igemm_spw_body): layers of at least 96 output channels on large images
+      const int wtn = spw_wtn(a);
+      if (wtn) {
+        const size_t bytes = (size_t)(a.N / (16 * wtn)) * ((a.ntaps * (a.K / 16) + 1) / 2) * (size_t)(2 * 16 * wtn * 64);
+        if (unsigned char* img = scratch_reserve(st, bytes)) {
+          ++g_cnt[CNT_SP_WIDE];
+          if (launch_spw_kernel(a, wtn, 1, img, st) == 0) return 0;
+        }
+      }
     }
     if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
     return launch_sp(ns, a, pl, st);
@@ -1127,7 +1154,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

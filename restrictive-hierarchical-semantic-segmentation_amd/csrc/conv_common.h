@@ -104,6 +104,7 @@ int launch_igemm_group_f32(const IgemmGroup& g, int wtm, int wtn, int kc, hipStr
 int launch_wgrad_f32(const WgradArgs& a, int tn, int tk, int pix, int db, int target, hipStream_t st);   // conv_wgrad_f32.hip
 int launch_wgrad_group_f32(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st);
 int launch_sp_kernel(int ns, const IgemmArgs& a, const SpPlan& pl, hipStream_t st);                  // conv_sp_im2col.hip
+int launch_spw_kernel(const IgemmArgs& a, int wtn, int ksplit, unsigned char* img, hipStream_t st);
 int launch_sp_group_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, bool full, hipStream_t st);
 int launch_patch_sp_kernel(int ns, const IgemmArgs& a, int wtn, int cs, int flip, int blocks, int ntotal, hipStream_t st);  // conv_sp_patch.hip
 int launch_sp_pgroup_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, int cs, int flip, hipStream_t st);               // conv_sp_pgroup.hip

@@ -22,6 +22,7 @@
 // XOR-swizzled 16-byte slots, double buffered, one barrier per slab.  The k index inside a slab is
 // permuted the same way on both operands: k = 8g+j  <->  unit j>>2, channel 4g + (j&3).
 #pragma once
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -408,6 +409,299 @@ __global__ __launch_bounds__(256) void igemm_sp_group_kernel(IgemmGroup grp) {
   const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
   const int tiles = grp.tiles[gi];
   igemm_sp_body<NS, WTM, WTN>(grp.a[gi], lds, local % tiles, tiles, local / tiles, grp.ksplit[gi]);
+}
+
+// --------------------------------------------------------------------------- im2col body, wide channel tiles, pre-split weights
+// igemm_sp_body splits BOTH operands on the fly: per 32-wide slab and wave ~72 VALU for its pixel rows and 18 per weight
+// granule, next to only 18 MFMAs on a 128 x 48 tile -- the body is VALU-bound (MFMA-busy 0.10-0.24), and a wide layer
+// (720 -> 720) repeats the pixel split for each of its 15 channel tiles.  This body (fp16x2 only) takes the weights
+// PRE-SPLIT from an image laid out slab by slab exactly like its LDS buffer (sp_weight_image_im2col_kernel, one small
+// launch per convolution into the caller's scratch ring, as for the wave-specialised 3x3 kernels), so the weight side is
+// a 16-byte copy per granule, and widens the channel tile to 16*WTN = 96 ... 240: the pixel split is amortised over up to
+// 15 MFMA column tiles (90 MFMAs per slab and wave at 128 x 240) and the pixel operand is pulled through L2 3 times
+// instead of 15.  Same reduction order per accumulator as igemm_sp_body (slab by slab, products in sp_mma order): results
+// are bit-identical to it for ks_n == 1.
+template <int WTN>
+struct SpwLds {
+  static constexpr int BN = 16 * WTN;
+  static constexpr int WPIECE = BN * 64, WSTAGE = 2 * WPIECE;
+  static constexpr int BYTES = 2 * WSTAGE;          // double buffered
+};
+
+// image of one convolution: [channel tile][slab over the full unit list][WSTAGE]
+#ifdef HRSEG_TU_IM2COL
+__global__ __launch_bounds__(256) void sp_weight_image_im2col_kernel(const float* __restrict__ w, unsigned char* __restrict__ img,
+                                                                     int K, int T, int ntaps, unsigned long long wtap_pk,
+                                                                     float wscale, int BN, int nslabs) {
+  const int slab = blockIdx.x % nslabs, nt = blockIdx.x / nslabs;
+  const int kch = K >> 4, nunits = ntaps * kch;
+  unsigned char* dst = img + (size_t)blockIdx.x * (size_t)(2 * BN * 64);
+  for (int f = threadIdx.x; f < BN * 8; f += 256) {
+    const int n = f >> 3, unit = (f >> 2) & 1, gq = f & 3;
+    const int u = 2 * slab + unit;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (u < nunits) {
+      const int t = u / kch, c = u - t * kch;
+      const int wt = (int)((wtap_pk >> (4 * t)) & 15);
+      v = *reinterpret_cast<const f32x4*>(w + ((size_t)(nt * BN + n) * T + wt) * K + c * 16 + 4 * gq);
+    }
+    u32x2 pc[2];
+    sp_split4<4>(v, pc, wscale);
+    const int o = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
+    *reinterpret_cast<u32x2*>(dst + o) = pc[0];
+    *reinterpret_cast<u32x2*>(dst + BN * 64 + o) = pc[1];
+  }
+}
+
+#endif
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void igemm_spw_body(const IgemmArgs& p, unsigned char* lds, const int bid, const int nblk,
+                                               const int ks_idx, const int ks_n) {
+  constexpr int NS = 4;
+  constexpr int BM = 64 * WTM, BN = 16 * WTN;
+  constexpr int WPIECE = SpwLds<WTN>::WPIECE, WSTAGE = SpwLds<WTN>::WSTAGE;
+  constexpr int W16 = WSTAGE / 16;                 // 16-byte granules of a pre-split slab
+  constexpr int W_LOADS = (W16 + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = p.N / BN;
+  const int wg = xcd_remap(bid, nblk);
+  const int nt = wg % ntn;
+  const int m0 = (wg / ntn) * BM, n0 = nt * BN;
+
+  float xscale, xinv;
+  sp_pow2_scale(p.xmax, xscale, xinv);
+  const float oscale = xinv * p.wscale_inv;
+
+  const int kch = p.K >> 4;
+  const int nunits = p.ntaps * kch;
+  const int nslabs_all = (nunits + 1) >> 1;
+  const int per = (nslabs_all + ks_n - 1) / ks_n;
+  const int s_lo = ks_idx * per;
+  const int s_hi = min(s_lo + per, nslabs_all);
+  const int nslabs = s_hi - s_lo;
+
+  const int hw = p.Ho * p.Wo;
+  const int b0 = m0 / hw;
+  const long tap0 = (long)p.oy_min * p.Wi + p.ox_min;          // <= 0
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + ((long)b0 * p.Hi * p.Wi + tap0) * p.ldx,
+                                              (size_t)((long)(p.B - b0) * p.Hi * p.Wi - tap0) * p.ldx * 4);
+  const __amdgpu_buffer_rsrc_t rwi = make_rsrc(reinterpret_cast<const float*>(p.wimg), (size_t)ntn * nslabs_all * WSTAGE);
+
+  unsigned voff[WTM];
+  int inval[WTM];
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    const int row = m0 + wave * 16 * WTM + 16 * m + r16;
+    if (row < p.M) {
+      const int b = fdiv(row, hw, p.rcp_hw);
+      const int rem = row - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.sy, ix0 = ox * p.sx;
+      voff[m] = ((unsigned)((b - b0) * p.Hi * p.Wi + iy0 * p.Wi + ix0) * (unsigned)p.ldx + 4u * g) * 4u;
+      int bad = 0;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int iy = iy0 + (int)((p.offy_pk >> (4 * t)) & 15) - 8, ix = ix0 + (int)((p.offx_pk >> (4 * t)) & 15) - 8;
+        bad |= ((iy < 0) | (iy >= p.Hi) | (ix < 0) | (ix >= p.Wi)) ? (1 << t) : 0;
+      }
+      inval[m] = bad;
+    } else {
+      voff[m] = 0;
+      inval[m] = -1;
+    }
+  }
+
+  constexpr int D = SP_DEPTH;
+  int u_next = 2 * s_lo;
+  const int u_end = min(nunits, 2 * s_hi);
+  unsigned w_off = (unsigned)(nt * nslabs_all + s_lo) * (unsigned)WSTAGE;        // image offset of the next slab to load
+  const unsigned w_end = (unsigned)(nt * nslabs_all + s_hi) * (unsigned)WSTAGE;
+  f32x4 ra[D][WTM][2], rwt[D][W_LOADS];
+  auto issue_loads = [&](f32x4 (&ra)[WTM][2], f32x4 (&rwt)[W_LOADS]) {
+    unsigned soff[2];
+    int tapbit[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = u_next + h;
+      const bool live = u < u_end;
+      const int t = live ? u / kch : 0;
+      const int c = u - t * kch;
+      const int dy = (int)((p.offy_pk >> (4 * t)) & 15) - 8 - p.oy_min, dx = (int)((p.offx_pk >> (4 * t)) & 15) - 8 - p.ox_min;
+      soff[h] = live ? (unsigned)((dy * p.Wi + dx) * p.ldx + 16 * c) * 4u : 0u;
+      tapbit[h] = live ? t : 31;
+    }
+    const bool live0 = u_next < u_end, live1 = u_next + 1 < u_end;
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int oob = __builtin_amdgcn_sbfe(inval[m], tapbit[h], 1) | ((h == 1 ? !live1 : !live0) ? -1 : 0);
+        ra[m][h] = buf_load4(rx, voff[m] | (unsigned)oob, (int)soff[h]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+      const int f = tid + 256 * i;
+      rwt[i] = buf_load4(rwi, (f < W16 && w_off < w_end) ? w_off + (unsigned)f * 16u : HRSEG_BUF_OOB, 0);
+    }
+    u_next += 2;
+    w_off += WSTAGE;
+  };
+
+  constexpr int G = (WTN % 3 == 0) ? 3 : 2, NG = WTN / G;       // channel tiles per MFMA group, groups per slab
+  constexpr int MG = G * WTM * 3;                                 // MFMAs of a group
+  static_assert(WTN % G == 0, "channel tiles per block: a multiple of the group size");
+  constexpr int HPG = (MG - 2 * G - 2) / 4;                       // half row splits (four steps each) a group's MFMAs carry
+  static_assert(2 * NG >= W_LOADS && NG * HPG >= 2 * WTM, "a slab's MFMAs carry the whole staging of the next slab as fillers");
+  unsigned xfu[2][WTM][2][4];        // pixel fragments (raw dwords) of the current slab and of the next one: [set][row tile][piece]
+  f32x4 acc[WTN][WTM];
+#pragma unroll
+  for (int n = 0; n < WTN; ++n)
+#pragma unroll
+    for (int m = 0; m < WTM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int foff = r16 * 64 + lds_slot(r16, g) * 16;
+
+  // prologue: D slabs in flight; slab s_lo staged (weights copied into buffer 0, pixel rows split into fragment set 0)
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_loads(ra[d], rwt[d]);
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    const int f = tid + 256 * i;
+    if (f < W16) *reinterpret_cast<f32x4*>(lds + f * 16) = rwt[0][i];
+  }
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    bf16x8 t[2];
+    sp_split8<NS>(ra[0][m][0], ra[0][m][1], t, xscale);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const u32x4 u = __builtin_bit_cast(u32x4, t[q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xfu[0][m][q][e] = u[e];
+    }
+  }
+  __syncthreads();
+  // One slab: slab s lives in register set R = s % D and LDS buffer / fragment set C = s & 1 (the loop below is unrolled
+  // 2*D times so that both are compile-time).  One wave per SIMD runs this body, so nothing hides an instruction that is
+  // not issued in the shadow of an MFMA (an MFMA holds the vector issue for 8 of its 16 cycles): every piece of the next
+  // slab's staging is a FILLER placed behind a particular MFMA of the current slab --
+  //   MFMA 0 .. 2G-1 of group k      one ds_read_b128 each: the weight fragments of group k+1
+  //   MFMA 2G, 2G+1 of group k       one 16-byte copy each of the pre-split weight slab s+1 into the other LDS buffer
+  //   MFMA 2G+2 ... of group k       the four steps (scale, hi piece, residual, lo piece) of a half row split of slab s+1
+  // -- pinned there by sched_barrier (machine scheduler) and by passing each piece's inputs through an empty asm (IR passes
+  // would otherwise hoist the whole split to the top of the slab, where it runs with the matrix pipe idle: measured).
+  // Products run product-outermost inside a group (two MFMAs on one accumulator are G*WTM apart).
+  auto slab = [&](auto Rc, auto Cc) {
+    constexpr int R = decltype(Rc)::value, C = decltype(Cc)::value, RN = (R + 1) % D;
+    issue_loads(ra[R], rwt[R]);                          // slab s + D; set R held slab s, staged a slab ago
+    const unsigned char* base = lds + C * WSTAGE;
+    unsigned char* nbase = lds + (C ^ 1) * WSTAGE;
+    bf16x8 wf[2][G][2];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) wf[0][j][q] = *reinterpret_cast<const bf16x8*>(base + q * WPIECE + j * 1024 + foff);
+    bf16x8 xcur[WTM][2];
+#pragma unroll
+    for (int m = 0; m < WTM; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        xcur[m][q] = __builtin_bit_cast(bf16x8, (u32x4){xfu[C][m][q][0], xfu[C][m][q][1], xfu[C][m][q][2], xfu[C][m][q][3]});
+    float hx[4];                   // the half row split in flight
+    unsigned hhi[2];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int m = 0; m < WTM; ++m) {
+            const int i = (pr * G + j) * WTM + m;       // MFMA index inside the group
+            acc[k * G + j][m] = sp_mma_p<NS>(pr, wf[k & 1][j], xcur[m], acc[k * G + j][m]);
+            if (i < 2 * G) {
+              if (k + 1 < NG) {
+                const int jj = i >> 1, q = i & 1;
+                wf[(k + 1) & 1][jj][q] = *reinterpret_cast<const bf16x8*>(base + q * WPIECE + ((k + 1) * G + jj) * 1024 + foff);
+              }
+            } else if (i < 2 * G + 2) {
+              const int n = 2 * k + (i - 2 * G);
+              if (n < W_LOADS) {
+                const int f = tid + 256 * n;
+                asm volatile("" : "+v"(rwt[RN][n]));
+                if (f < W16) *reinterpret_cast<f32x4*>(nbase + f * 16) = rwt[RN][n];
+              }
+            } else if (i < 2 * G + 2 + 4 * HPG && k * HPG + (i - (2 * G + 2)) / 4 < 2 * WTM) {
+              const int h = k * HPG + (i - (2 * G + 2)) / 4;
+              const int hm = h >> 1, hu = h & 1, st = (i - (2 * G + 2)) & 3;            // row tile, unit, step
+              if (st == 0) {
+                asm volatile("" : "+v"(ra[RN][hm][hu]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hx[e] = ra[RN][hm][hu][e] * xscale;
+              } else if (st == 1) {
+                hhi[0] = sp_pack_f16_rtz(hx[0], hx[1]);
+                hhi[1] = sp_pack_f16_rtz(hx[2], hx[3]);
+              } else if (st == 2) {
+                hx[0] -= sp_f16_lo(hhi[0]); hx[1] -= sp_f16_hi(hhi[0]);
+                hx[2] -= sp_f16_lo(hhi[1]); hx[3] -= sp_f16_hi(hhi[1]);
+              } else {
+                xfu[C ^ 1][hm][0][2 * hu] = hhi[0];
+                xfu[C ^ 1][hm][0][2 * hu + 1] = hhi[1];
+                xfu[C ^ 1][hm][1][2 * hu] = sp_pack_f16_rne(hx[0], hx[1]);
+                xfu[C ^ 1][hm][1][2 * hu + 1] = sp_pack_f16_rne(hx[2], hx[3]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+    }
+    __syncthreads();
+  };
+  static_assert(D == 3, "unrolled by hand: 2 * D slabs per trip");
+  for (int s0 = 0; s0 < nslabs; s0 += 6) {       // (slabs past the slice are zeros: every load of theirs was out of range)
+    slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    slab(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    slab(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+  }
+
+  const bool split = ks_n > 1;
+#pragma unroll
+  for (int m = 0; m < WTM; ++m) {
+    const int row = m0 + wave * 16 * WTM + 16 * m + r16;
+    if (row >= p.M) continue;
+    size_t pix = row;
+    if (!p.direct_out) {
+      const int b = fdiv(row, hw, p.rcp_hw);
+      const int rem = row - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      pix = (size_t)(b * p.Hy + oy * p.oys + p.oy0) * p.Wy + ox * p.oxs + p.ox0;
+    }
+    float* yrow = p.y + pix * p.ldy;
+    // (the accumulators leave no registers for reading every addend ahead of the first store, as igemm_sp_body does)
+#pragma unroll
+    for (int n = 0; n < WTN; ++n) {
+      const int ch = n0 + 16 * n + 4 * g;
+      f32x4 v = acc[n][m] * oscale;
+      if (p.bias && ks_idx == 0) v += *reinterpret_cast<const f32x4*>(p.bias + ch);
+      if (split) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
+      } else {
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        *reinterpret_cast<f32x4*>(yrow + ch) = v;
+      }
+    }
+  }
+}
+
+template <int WTM, int WTN>
+__global__ __launch_bounds__(256) void igemm_spw_kernel(IgemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpwLds<WTN>::BYTES];
+  igemm_spw_body<WTM, WTN>(p, lds, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
 }
 
 // --------------------------------------------------------------------------- weight gradient

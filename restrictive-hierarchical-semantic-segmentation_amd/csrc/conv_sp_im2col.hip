@@ -1,4 +1,5 @@
 // Split-precision implicit GEMM, im2col body (1x1, stride 2, narrow images): kernel instances + launchers.
+#define HRSEG_TU_IM2COL
 #include "conv_common.h"
 #include "conv_sp.h"
 
@@ -34,4 +35,19 @@ static int launch_sp_group(const IgemmGroup& g, int wtm, int wtn, bool full, hip
 int launch_sp_group_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, bool full, hipStream_t st) {
   return ns == 4 ? launch_sp_group<4>(g, wtm, wtn, full, st) : ns == 3 ? launch_sp_group<3>(g, wtm, wtn, full, st)
        : ns == 2 ? launch_sp_group<2>(g, wtm, wtn, full, st) : launch_sp_group<1>(g, wtm, wtn, full, st);
+}
+
+// wide channel tiles with pre-split weights (fp16x2): builds the weight image into `img`, then the convolution
+int launch_spw_kernel(const IgemmArgs& a, int wtn, int ksplit, unsigned char* img, hipStream_t st) {
+  const int BN = 16 * wtn;
+  const int nslabs = (a.ntaps * (a.K / 16) + 1) / 2;
+  hipLaunchKernelGGL(sp_weight_image_im2col_kernel, dim3((a.N / BN) * nslabs), dim3(256), 0, st, a.w, img, a.K, a.T, a.ntaps,
+                     a.wtap_pk, a.wscale, BN, nslabs);
+  IgemmArgs b = a;
+  b.wimg = img;
+  const dim3 grid(ceil_div(a.M, 128) * (a.N / BN), ksplit);
+#define SPW(N_) if (wtn == N_) { hipLaunchKernelGGL((igemm_spw_kernel<2, N_>), grid, dim3(256), 0, st, b); return 0; }
+  SPW(6) SPW(8) SPW(12) SPW(15)
+#undef SPW
+  return 1;
 }

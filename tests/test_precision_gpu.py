@@ -198,3 +198,51 @@ def test_configs4_geometry_step_properties_in_bf16():
             assert int(b) == 4 * 4, n          # 4 level passes per forward (D1), four training-mode forwards
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     print("configs[4] geometry, bf16 convs: losses", losses, "peak mem %.1f GB" % (torch.cuda.max_memory_allocated() / 2**30))
+
+
+# Cin, Cout, k, s, H, W, B: layers of >= 96 output channels (forward) or input channels (data gradient) that the wide-tile
+# im2col body takes -- 1x1 (the 720-channel head layer's shape class, layer1's bottleneck convs), stride-2 3x3, 16-channel
+# units that do not fill the last slab, ragged pixel counts
+WIDE_CASES = [(144, 240, 1, 1, 37, 41, 3), (64, 256, 1, 1, 50, 50, 2), (256, 96, 3, 2, 45, 45, 2), (48, 192, 3, 2, 61, 60, 2),
+              (240, 240, 1, 1, 33, 35, 2), (96, 96, 1, 1, 40, 40, 3)]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_wide_tile_im2col_body_bit_identical_to_the_narrow_one(case):
+    """igemm_spw_body (pre-split weight image, 96..240-channel tiles) adds the same products in the same order as
+    igemm_sp_body: identical bits for forward, data gradient and accumulation; both within the fp16x2 tolerance of torch"""
+    from hrseg_amd import _lib, ops
+    cin, cout, k, s, H, W, B = case
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, bias, stride=s, padding=(k - 1) // 2)
+    dy = torch.randn(y_ref.shape, generator=g) * 1e-3
+    y_ref.backward(dy)
+    xd, wd, dyd = _nhwc(x), w.permute(0, 2, 3, 1).contiguous().cuda(), _nhwc(dy)
+    gmax = dyd.abs().max().reshape(1).repeat(64)
+    wt = ops.weight_transpose(wd, cout, k * k, cin)
+    res = {}
+    try:
+        for wide in (1, 0):
+            _lib.tune(sp_wide=wide, sp_wide_min_blocks=1, sp_ksplit=1)
+            _lib.launch_count(None, reset=True)
+            y = ops.conv_fwd(xd, wd, bias.cuda(), k, s, prec=pr)
+            n_fwd = _lib.launch_count("sp_wide", reset=True)
+            dx = ops.conv_dgrad(dyd, wt, xd.shape, k, s, prec=pr, gmax=gmax)
+            dx2 = ops.conv_dgrad(dyd, wt, xd.shape, k, s, out=dx.clone(), accumulate=True, prec=pr, gmax=gmax)
+            n_bwd = _lib.launch_count("sp_wide", reset=True)
+            res[wide] = (y, dx, dx2, n_fwd, n_bwd)
+    finally:
+        _lib.tune(sp_wide=1, sp_wide_min_blocks=0, sp_ksplit=0)
+    assert res[1][3] == 1 and res[0][3] == 0 and res[0][4] == 0
+    if s == 1:
+        assert res[1][4] == 2 or cin % 96                      # the data gradient of a 1x1 layer is a 1x1 layer over Cin
+    assert torch.equal(res[1][0], res[0][0]), "forward: wide and narrow bodies differ"
+    if s == 1:       # (a stride-2 data gradient is a grouped launch of four parity classes with split-K atomics: not bit-stable)
+        assert torch.equal(res[1][1], res[0][1]) and torch.equal(res[1][2], res[0][2]), "data gradient: wide and narrow differ"
+    assert _rel(_nchw(res[1][0]), y_ref) < TOL["fp16x2"]
+    assert _rel(_nchw(res[1][1]), xr.grad) < TOL["fp16x2"] and _rel(_nchw(res[1][2]), 2 * xr.grad) < TOL["fp16x2"]
