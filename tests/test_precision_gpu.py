@@ -228,7 +228,7 @@ def test_wide_tile_im2col_body_bit_identical_to_the_narrow_one(case):
     res = {}
     try:
         for wide in (1, 0):
-            _lib.tune(sp_wide=wide, sp_wide_min_blocks=1, sp_ksplit=1)
+            _lib.tune(sp_wide=2 * wide, sp_wide_min_blocks=1, sp_ksplit=1)      # (2: also reductions of a few slabs)
             _lib.launch_count(None, reset=True)
             y = ops.conv_fwd(xd, wd, bias.cuda(), k, s, prec=pr)
             n_fwd = _lib.launch_count("sp_wide", reset=True)
