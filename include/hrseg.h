@@ -201,6 +201,9 @@ typedef struct {
                                                         the running averages / num_batches_tracked
                                                         (0 or 1 = once; L = de-duplicated level
                                                         passes, see Models/models.py)               */
+  unsigned char* relu_mask;                          /* optional out, [npix][C/4] bytes: bit j of byte (pixel, q) =
+                                                        channel 4q+j passed the ReLU; the backward of a layer WITH a
+                                                        residual reads it (hrseg_bn_bwd_t.relu_mask) instead of z    */
   int stat_ranks;                                    /* cross-rank statistics (opt-in synchronised BN): the
                                                         partial sums were all-reduced over this many ranks of
                                                         equal shards between the statistics and the finalize
@@ -228,6 +231,9 @@ typedef struct {
                                                         level passes), each normalised on its own: the
                                                         batch means of the backward are per segment;
                                                         must divide nchunks and npix (0 or 1 = plain)  */
+  const unsigned char* relu_mask;                    /* optional: the forward's ReLU mask bytes; given, neither z is
+                                                        read nor the mask recomputed (4 B per element less per pass
+                                                        on layers with a residual)                                  */
   int sum_ranks;                                     /* cross-rank statistics: the partial sums were all-reduced
                                                         over this many ranks between the reduce and the finalize
                                                         phase; the finalize divides them by it, so that the batch

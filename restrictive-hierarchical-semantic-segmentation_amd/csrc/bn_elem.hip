@@ -629,7 +629,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
                                            int ldz, int relu, const float* __restrict__ yy, int ldy,
                                            const float* __restrict__ coef, long npix, int C,
                                            double* __restrict__ partial, int chunk, int nchunks, bool bwd,
-                                           double* red, int nseg = 1) {
+                                           double* red, int nseg = 1, const unsigned char* __restrict__ bmask = nullptr) {
   // forward: sums of a0 and a0^2; backward: sums of g and g*xhat with g = a0 * (zmask > 0 if relu)
   // nseg > 1: the pixel range is nseg equal segments (the batched level passes); a chunk never
   // straddles two segments (nchunks is a multiple of nseg)
@@ -655,6 +655,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long pix0 = lo + L.pl; pix0 < hi; pix0 += (long)U * L.P) {
       f32x4 v[U], yv[U], zz[U];
+      unsigned bm[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long pix = pix0 + (long)u * L.P;
@@ -662,7 +663,8 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
         v[u] = ok ? ld4(a0 + pix * ld0 + 4 * L.cq) : zero;
         if (bwd) {
           yv[u] = ok ? ld4(yy + pix * ldy + 4 * L.cq) : mean;
-          if (relu && zmask) zz[u] = ok ? ld4(zmask + pix * ldz + 4 * L.cq) : zero;
+          if (relu && bmask) bm[u] = ok ? bmask[pix * L.Q + L.cq] : 0u;
+          else if (relu && zmask) zz[u] = ok ? ld4(zmask + pix * ldz + 4 * L.cq) : zero;
         }
       }
 #pragma unroll
@@ -672,7 +674,10 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
           s2 += v[u] * v[u];
         } else {
           f32x4 gv = v[u];
-          if (relu) {
+          if (relu && bmask) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = ((bm[u] >> j) & 1u) ? gv[j] : 0.f;
+          } else if (relu) {
             // z not given: the forward had no residual, so z > 0 <=> y*scale+shift > 0 (4 bytes less per element)
             const f32x4 zc = zmask ? zz[u] : bn_affine(yv[u], sc, sh);
 #pragma unroll
@@ -779,6 +784,9 @@ __global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
     f32x4 v = bn_affine(ld4(p.y + pix * p.ldy + 4 * L.cq), sc, sh);
     if (p.residual) v += ld4(p.residual + pix * p.ldr + 4 * L.cq);
     if (p.relu) {
+      // one byte per (pixel, channel quad): bit j = "channel 4q+j passed the ReLU".  With a residual the backward cannot
+      // recompute the mask from y alone; reading this byte instead of z saves it 4 B per element, twice
+      if (p.relu_mask) p.relu_mask[pix * L.Q + L.cq] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
     }
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   // the |dy| slots the apply kernel raises with atomicMax start from zero: reset here, two launches earlier on the stream
   if (local == 0 && threadIdx.x < 64 && p.dy_absmax) p.dy_absmax[threadIdx.x] = 0.f;
   stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
-             nseg);
+             nseg, p.relu_mask);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
@@ -848,7 +856,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(BnBwdG g, int e
   for (long pix = seg * seg_pix + (long)local * L.P + L.pl; pix < (seg + 1) * seg_pix; pix += (long)nblk * L.P) {
     f32x4 gg = ld4(p.dz + pix * p.lddz + 4 * L.cq);
     const f32x4 yv = ld4(p.y + pix * p.ldy + 4 * L.cq);
-    if (p.relu) {
+    if (p.relu && p.relu_mask) {
+      const unsigned bm = p.relu_mask[pix * L.Q + L.cq];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gg[j] = ((bm >> j) & 1u) ? gg[j] : 0.f;
+    } else if (p.relu) {
       const f32x4 zz = p.z ? ld4(p.z + pix * p.ldz + 4 * L.cq) : bn_affine(yv, scale, shift);
 #pragma unroll
       for (int j = 0; j < 4; ++j) gg[j] = zz[j] > 0.f ? gg[j] : 0.f;

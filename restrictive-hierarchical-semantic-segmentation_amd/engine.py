@@ -30,6 +30,7 @@ _SIDE = {}
 
 
 _SIDE_ENABLED = None
+_RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the backward of residual layers reads z for its ReLU mask
 
 
 def wgrad_stream(device):
@@ -230,10 +231,15 @@ class Recorder:
             ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
                                     [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
                                     [c.out_channels for _, c, _, _ in items], prec=self.prec)
+        # layers with a residual and a ReLU: the backward's mask is not recomputable from y; the forward leaves it as one
+        # byte per channel quad (hrseg_bn_fwd_t.relu_mask) so that the backward reads 1/16 of what reading z costs
+        masks = [torch.empty((y.shape[0] * y.shape[1] * y.shape[2], y.shape[3] // 4), dtype=torch.uint8, device=y.device)
+                 if (self.record and _RELU_MASK and relus[i] and it[3] is not None) else None
+                 for i, (it, y) in enumerate(zip(items, ys))]
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
                          residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
-                         stat_div=self.bn_segments,
+                         stat_div=self.bn_segments, relu_mask=masks[i],
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
         zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync)
@@ -261,7 +267,8 @@ class Recorder:
                         dres_acc = True
                     dres = res.grad
                 # without a residual the ReLU mask is recomputed from y: the backward never reads z
-                bw.append(dict(dz=dz, z=z.data if (relus[i] and res is not None) else None, relu=relus[i], y=y, coef=coef,
+                bw.append(dict(dz=dz, z=z.data if (relus[i] and res is not None and masks[i] is None) else None,
+                               relu_mask=masks[i], relu=relus[i], y=y, coef=coef,
                                dgamma=bn.weight._hr_gstore,
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments,
                                dy_absmax=gmaxs[i]))

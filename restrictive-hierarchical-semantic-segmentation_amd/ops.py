@@ -283,6 +283,7 @@ def bn_fwd_group(items, training, sync=None):
         a.stat_div = int(it.get("stat_div", 1))
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
+        a.relu_mask = ptr(it.get("relu_mask"))
         a.stat_ranks = ranks
         if training:
             nch = _nchunks(npix, Cn)
@@ -350,6 +351,7 @@ def bn_bwd_group(items, eval_mode, sync=None):
         a.dres_accumulate = int(bool(it.get("dres_accumulate", False)))
         a.npix, a.C, a.partial, a.nchunks = npix, Cn, ptr(part), nch
         a.dy_absmax = ptr(it.get("dy_absmax"))
+        a.relu_mask = ptr(it.get("relu_mask"))
     if sync is not None:
         import torch.distributed as dist
         call("hrseg_bn_bwd_group_phases", n, arr, 0, 1)

@@ -650,3 +650,34 @@ def test_first_layer_direct_conv_kernels(cin, stride, bias):
     assert float((dx.permute(0, 3, 1, 2).cpu() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
     ops.conv_dgrad(dyd, wd.reshape(cout, 9, cin), xd.shape, 3, stride, out=dx, accumulate=True)
     assert float((dx.permute(0, 3, 1, 2).cpu() - 2 * xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
+
+
+def test_bn_backward_with_relu_mask_bytes_equals_reading_z():
+    """layers with a residual: the forward leaves its ReLU mask as one byte per channel quad; the backward that reads those
+    bytes must give the bits of the backward that reads z"""
+    from hrseg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 3, 21, 17, 48
+    y = torch.randn(B, H, W, C, generator=g).cuda()
+    res = torch.randn(B, H, W, C, generator=g).cuda()
+    dz = torch.randn(B, H, W, C, generator=g).cuda()
+    mask = torch.empty((B * H * W, C // 4), dtype=torch.uint8, device="cuda")
+
+    def item(**kw):
+        return dict(y=y, gamma=torch.ones(C, device="cuda") * 1.3, beta=torch.zeros(C, device="cuda") - 0.1,
+                    rm=torch.zeros(C, device="cuda"), rv=torch.ones(C, device="cuda"),
+                    nbt=torch.zeros((), dtype=torch.int64, device="cuda"), momentum=0.1, eps=1e-5, residual=res, relu=True, **kw)
+    (z, coef), = ops.bn_fwd_group([item(relu_mask=mask)], True)
+    want_bits = (z > 0).view(B * H * W, C // 4, 4).to(torch.uint8)
+    want = want_bits[..., 0] | (want_bits[..., 1] << 1) | (want_bits[..., 2] << 2) | (want_bits[..., 3] << 3)
+    assert torch.equal(mask, want)
+    outs = []
+    for use_mask in (True, False):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dres = torch.empty_like(y)
+        d = dz.clone()
+        ops.bn_bwd_group([dict(dz=d, z=None if use_mask else z, relu_mask=mask if use_mask else None, relu=True, y=y, coef=coef,
+                               dgamma=dg, dbeta=db, dres=dres, dres_accumulate=False)], False)
+        outs.append((d, dg, db, dres))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
