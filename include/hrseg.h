@@ -264,6 +264,11 @@ int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, int Wi, int
 /* max|x| of an NHWC tensor: slot (block % 64) of the 64-float DEVICE array out64 (zeroed by the caller) is raised to
  * the maximum of its blocks; NaN counts as +Inf.  Range check in front of FP16X2 convolutions (see above). */
 int hrseg_absmax(const float* x, int ldx, long npix, int C, float* out64, hrseg_stream_t stream);
+/* HRNet fuse sum (models.py:527-542) in one pass: out = relu?( sum of n_same (1..4) same-resolution NHWC terms + sum of
+ * n_low (0..3) terms bilinearly resized from Hi[j] x Wi[j] to H x W ); HOST arrays of pointers / strides / sizes */
+int hrseg_fuse_sum(int n_same, const float* const* same, const int* ld_same, int n_low, const float* const* low,
+                   const int* ld_low, const int* Hi, const int* Wi, float* out, int ldo, int B, int H, int W, int C,
+                   int align_corners, int relu, hrseg_stream_t stream);
 /* out = relu?(a + b) ; strided channel copy ; masked relu backward */
 int hrseg_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int relu,
               long npix, int C, hrseg_stream_t stream);

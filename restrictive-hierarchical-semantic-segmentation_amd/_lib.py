@@ -80,6 +80,7 @@ PROTOTYPES = {
     "hrseg_bilinear_fwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_bilinear_bwd": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_absmax": [_p, _i, _l, _i, _p, _p],
+    "hrseg_fuse_sum": [_i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hrseg_add": [_p, _i, _p, _i, _p, _i, _i, _l, _i, _p],
     "hrseg_copy": [_p, _i, _p, _i, _i, _l, _i, _p],
     "hrseg_relu_bwd": [_p, _i, _p, _i, _p, _i, _l, _i, _p],

@@ -392,6 +392,52 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
   }
 }
 
+// HRNet fuse sum (Models/models.py:527-542) in ONE pass: out = relu?( sum of same-resolution terms + sum of bilinearly
+// up-sampled low-resolution terms ).  The chain of add / copy / accumulating-bilinear launches it replaces re-reads and
+// re-writes `out` once per term.
+struct FuseSumArgs {
+  int n_same, n_low;
+  const float* same[4]; int ld_same[4];
+  const float* low[3]; int ld_low[3]; int Hi[3], Wi[3];
+  float sh[3], sw[3];
+  float* out; int ldo;
+  int B, H, W, C, align, relu;
+};
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseSumArgs a) {
+  const Lanes L = make_lanes(a.C);
+  if (!L.active) return;
+  const long npix = (long)a.B * a.H * a.W;
+  FOR_PIXELS(pix, L, npix) {
+    f32x4 v = ld4(a.same[0] + pix * a.ld_same[0] + 4 * L.cq);
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < a.n_same) v += ld4(a.same[i] + pix * a.ld_same[i] + 4 * L.cq);
+    if (a.n_low) {
+      const int b = (int)(pix / ((long)a.H * a.W));
+      const int rem = (int)(pix - (long)b * a.H * a.W);
+      const int oy = rem / a.W, ox = rem - oy * a.W;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < a.n_low) {
+          int y0, y1, x0, x1;
+          float ly0, ly1, lx0, lx1;
+          src_index(oy, a.sh[j], a.Hi[j], a.align, y0, y1, ly0, ly1);
+          src_index(ox, a.sw[j], a.Wi[j], a.align, x0, x1, lx0, lx1);
+          const int ld = a.ld_low[j], Wi = a.Wi[j];
+          const float* p = a.low[j] + (size_t)b * a.Hi[j] * Wi * ld + 4 * L.cq;
+          const f32x4 v00 = ld4(p + ((size_t)y0 * Wi + x0) * ld), v01 = ld4(p + ((size_t)y0 * Wi + x1) * ld);
+          const f32x4 v10 = ld4(p + ((size_t)y1 * Wi + x0) * ld), v11 = ld4(p + ((size_t)y1 * Wi + x1) * ld);
+          v += ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        }
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st4(a.out + pix * a.ldo + 4 * L.cq, v);
+  }
+}
+
 // gather form of the transpose: every input pixel sums the output pixels that read it (no atomics,
 // deterministic).  An 8x resize gives each input pixel an ~18x18 footprint and only a few thousand input
 // pixels: RS sub-lanes per pixel split the footprint rows (thread = channel quad x pixel lane x row split)
@@ -1029,6 +1075,32 @@ extern "C" int hrseg_bilinear_bwd(const float* dout, int lddout, int B, int Hi, 
   if (rs == 1) HRSEG_BIL(1); else if (rs == 2) HRSEG_BIL(2); else if (rs == 4) HRSEG_BIL(4); else HRSEG_BIL(8);
 #undef HRSEG_BIL
   HRSEG_LAUNCH_CHECK("bilinear_bwd");
+  return 0;
+}
+
+extern "C" int hrseg_fuse_sum(int n_same, const float* const* same, const int* ld_same, int n_low, const float* const* low,
+                              const int* ld_low, const int* Hi, const int* Wi, float* out, int ldo, int B, int H, int W, int C,
+                              int align_corners, int relu, hrseg_stream_t stream) {
+  if (int e = check_c(C, "hrseg_fuse_sum")) return e;
+  HRSEG_CHECK_ARG(n_same >= 1 && n_same <= 4 && n_low >= 0 && n_low <= 3 && same && ld_same && out && B > 0 && H > 0 && W > 0,
+                  "hrseg_fuse_sum: 1..4 same-resolution terms and 0..3 low-resolution terms");
+  HRSEG_CHECK_ARG(n_low == 0 || (low && ld_low && Hi && Wi), "hrseg_fuse_sum: low-resolution terms need their geometry");
+  FuseSumArgs a{};
+  a.n_same = n_same; a.n_low = n_low;
+  for (int i = 0; i < n_same; ++i) {
+    HRSEG_CHECK_ARG(same[i] && ld_same[i] >= C && ld_same[i] % 4 == 0, "hrseg_fuse_sum: bad same-resolution term %d", i);
+    a.same[i] = same[i]; a.ld_same[i] = ld_same[i];
+  }
+  for (int j = 0; j < n_low; ++j) {
+    HRSEG_CHECK_ARG(low[j] && ld_low[j] >= C && ld_low[j] % 4 == 0 && Hi[j] > 0 && Wi[j] > 0, "hrseg_fuse_sum: bad low-resolution term %d", j);
+    a.low[j] = low[j]; a.ld_low[j] = ld_low[j]; a.Hi[j] = Hi[j]; a.Wi[j] = Wi[j];
+    a.sh[j] = resize_scale(Hi[j], H, align_corners);
+    a.sw[j] = resize_scale(Wi[j], W, align_corners);
+  }
+  a.out = out; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.C = C; a.align = align_corners; a.relu = relu;
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(fuse_sum_kernel, dim3(elem_grid(npix, C)), dim3(256), 0, (hipStream_t)stream, a);
+  HRSEG_LAUNCH_CHECK("fuse_sum");
   return 0;
 }
 

@@ -366,15 +366,18 @@ class Recorder:
         lows = [a for a, low in terms if low]
         ref = same[0]
         B, H, W, Cn = ref.data.shape
-        if len(same) >= 2:
-            out = ops.add(same[0].data, same[1].data, relu=(len(same) == 2 and not lows))
-            for i, a in enumerate(same[2:]):
-                ops.add(out, a.data, relu=(i == len(same) - 3 and not lows), out=out)
-        else:
-            out = torch.empty(ref.data.shape, dtype=torch.float32, device=ref.data.device)
-            ops.copy(ref.data, out)
-        for i, a in enumerate(lows):
-            ops.bilinear_fwd(a.data, out, H, W, 0, 0, align_corners, accumulate=True, relu=(i == len(lows) - 1))
+        if len(same) <= 4 and len(lows) <= 3:
+            out = ops.fuse_sum([a.data for a in same], [a.data for a in lows], relu=True, align_corners=align_corners)
+        else:                                   # (more terms than the one-pass kernel takes: the launch chain)
+            if len(same) >= 2:
+                out = ops.add(same[0].data, same[1].data, relu=(len(same) == 2 and not lows))
+                for i, a in enumerate(same[2:]):
+                    ops.add(out, a.data, relu=(i == len(same) - 3 and not lows), out=out)
+            else:
+                out = torch.empty(ref.data.shape, dtype=torch.float32, device=ref.data.device)
+                ops.copy(ref.data, out)
+            for i, a in enumerate(lows):
+                ops.bilinear_fwd(a.data, out, H, W, 0, 0, align_corners, accumulate=True, relu=(i == len(lows) - 1))
         y = Act(out)
         if self.record:
             def bwd():

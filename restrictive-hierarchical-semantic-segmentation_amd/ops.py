@@ -397,6 +397,18 @@ def bilinear_bwd(dout, x_shape, Hr, Wr, py=0, px=0, align_corners=True, din=None
     return din
 
 
+def fuse_sum(same, lows, relu=True, align_corners=True):
+    """relu?(sum of same-resolution NHWC tensors + sum of bilinearly up-sampled low-resolution ones) in one pass"""
+    ref = same[0]
+    B, H, W, Cn = ref.shape
+    out = torch.empty(ref.shape, dtype=torch.float32, device=ref.device)
+    call("hrseg_fuse_sum", len(same), _lib.ptr_array(same), _lib.int_array([_ld(t) for t in same]), len(lows),
+         _lib.ptr_array(lows) if lows else None, _lib.int_array([_ld(t) for t in lows]) if lows else None,
+         _lib.int_array([t.shape[1] for t in lows]) if lows else None, _lib.int_array([t.shape[2] for t in lows]) if lows else None,
+         ptr(out), _ld(out), B, H, W, Cn, int(align_corners), int(relu))
+    return out
+
+
 def add(a, b, relu=False, out=None):
     if out is None:
         out = torch.empty(a.shape, dtype=torch.float32, device=a.device)

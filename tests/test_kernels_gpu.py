@@ -681,3 +681,35 @@ def test_bn_backward_with_relu_mask_bytes_equals_reading_z():
         outs.append((d, dg, db, dres))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_same,n_low", [(1, 3), (2, 2), (3, 1), (4, 0), (1, 1)])
+def test_fuse_sum_one_pass_equals_the_launch_chain(n_same, n_low):
+    """hrseg_fuse_sum (HRNet fuse layer sum, models.py:527-542: same-resolution terms + up-sampled low-resolution terms +
+    ReLU in one pass) adds in the order of the add / accumulating-bilinear chain it replaces: identical bits, and equal to
+    torch's F.interpolate(align_corners=True) sum within fp32 rounding"""
+    import torch.nn.functional as F
+    from hrseg_amd import ops
+    g = torch.Generator().manual_seed(10 * n_same + n_low)
+    B, H, W, C = 2, 39, 41, 48
+    same = [torch.randn(B, H, W, C, generator=g).cuda() for _ in range(n_same)]
+    lows = [torch.randn(B, (H + 2 ** (j + 1) - 1) // 2 ** (j + 1), (W + 2 ** (j + 1) - 1) // 2 ** (j + 1), C, generator=g).cuda()
+            for j in range(n_low)]
+    got = ops.fuse_sum(same, lows, relu=True, align_corners=True)
+    # the launch chain of engine.fuse_sum before the one-pass kernel
+    if n_same >= 2:
+        out = ops.add(same[0], same[1], relu=(n_same == 2 and not lows))
+        for i, a in enumerate(same[2:]):
+            ops.add(out, a, relu=(i == n_same - 3 and not lows), out=out)
+    else:
+        out = same[0].clone()
+    for i, a in enumerate(lows):
+        ops.bilinear_fwd(a, out, H, W, 0, 0, True, accumulate=True, relu=(i == n_low - 1))
+    if n_same == 1 and not lows:
+        out = torch.relu(out)
+    assert torch.equal(got, out)
+    ref = sum(t.permute(0, 3, 1, 2).cpu() for t in same)
+    for a in lows:
+        ref = ref + F.interpolate(a.permute(0, 3, 1, 2).cpu(), size=(H, W), mode="bilinear", align_corners=True)
+    ref = torch.relu(ref)
+    assert float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
