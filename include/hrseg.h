@@ -84,6 +84,9 @@ typedef struct {
   const float* grad_absmax; /* FP16X2, data / weight gradient: DEVICE array of 64 floats whose maximum is max|dy|
                                of the gradient operand (hrseg_bn_bwd_t.dy_absmax writes it; NULL: unscaled --
                                gradients below 6e-5 then lose precision)                                   */
+  const float* residual;    /* forward only, fused epilogue for inference with BatchNorm folded into the weights       */
+  int ldr, relu;            /* (hrseg_bn_fold): y = relu?(conv(x, w) + bias + residual[pixel*ldr + channel]); residual
+                               may be NULL; zero-initialised fields = plain convolution                               */
 } hrseg_conv_shape_t;
 
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */
@@ -162,6 +165,13 @@ int hrseg_bn_finalize(const double* partial, int nchunks, long npix, int C, cons
                       const float* beta, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, float eps, float* coef,
                       hrseg_stream_t stream);
+/* inference: BatchNorm (running statistics) folded into the convolution in front of it -- w_out[co][:] = w[co][:] * s,
+ * b_out[co] = (bias[co] - running_mean[co]) * s + beta[co] with s = gamma[co] / sqrt(running_var[co] + eps); `row` =
+ * k*k*Cin floats per output channel (OHWI), bias may be NULL.  With hrseg_conv_shape_t.residual / relu the whole
+ * conv + BN (+ residual) (+ ReLU) of models.py:113-118, 332-354 is then ONE launch. */
+int hrseg_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                  const float* running_var, float eps, int Cout, int row, float* w_out, float* b_out,
+                  hrseg_stream_t stream);
 /* eval mode: coef from running stats */
 int hrseg_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* coef,

@@ -207,6 +207,10 @@ class _EngineModel(nn.Module):
         # do WITH a process group, bn_helper.py:4-11 -- the reference itself never synchronises)
         self.sync_bn = os.environ.get("HRSEG_SYNC_BN", "0") == "1"
         self.sync_bn_group = None
+        # inference (eval mode, nothing recorded): BatchNorm folded into the convolution weights, residual + ReLU in the
+        # convolution epilogue (hrseg_bn_fold, hrseg_conv_shape_t.residual / relu).  HRSEG_BN_FOLD=0: separate BN launches
+        self.fold_bn = os.environ.get("HRSEG_BN_FOLD", "1") != "0"
+        self._param_epoch = 0            # bumped whenever weights or running statistics may have changed
 
     # -- parameters -------------------------------------------------------------------------
     def flatten_parameters(self, device=None):
@@ -239,11 +243,14 @@ class _EngineModel(nn.Module):
     def _run(self, x, record):
         run = _Run(self)
         prec = _lib.CONV_PRECISION[self.conv_dtype]
+        if self.training:
+            self._param_epoch += 1       # running statistics move
+        fold = self._fold() if (not self.training and not record) else None
         self._flat.wt_stale = True          # weights may have been updated since the last call
         x_nhwc = Act(ops.nchw_to_nhwc(x.contiguous().float()), needs_grad=False)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
-            rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync())
+            rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync(), fold=fold)
             feats = self._backbone(rec, x_nhwc)
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
@@ -288,7 +295,7 @@ class _EngineModel(nn.Module):
                 feats.slot = L               # its gradient is rows [L*B, (L+1)*B) of the stacked feature gradient
             elif shared is None:
                 rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1, prec=prec,
-                               sync=self._bn_sync())
+                               sync=self._bn_sync(), fold=fold)
                 if concat and L > 0:
                     # level L re-encodes cat(image, logits_{L-1}) through its own first convolution (cond_stems[L-1])
                     xin = Act(ops.concat_image_logits(x, run.logits[L - 1]), needs_grad=record)
@@ -319,6 +326,39 @@ class _EngineModel(nn.Module):
             run.probs.append(p)
             run.logits.append(z)
         return run
+
+    def _fold(self):
+        """(conv, bn) -> folded (weight, bias) for the inference path, cached on the conv until the parameters or the running
+        statistics may have changed (training forward, optimizer step, load_state_dict, or an in-place edit of the flat
+        buffer that torch's version counter sees)"""
+        if not self.fold_bn:
+            return None
+        token = (self._param_epoch, self._flat.data._version)
+
+        def fold(conv, bn):
+            hit = getattr(conv, "_hr_fold", None)
+            tok = token + (bn.running_mean._version, bn.running_var._version)
+            if hit is None or hit[0] != tok:
+                w_f, b_f = ops.bn_fold(conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
+                                       bn.weight._hr_store, bn.bias._hr_store, bn.running_mean, bn.running_var, bn.eps,
+                                       conv.out_channels)
+                # fp16x2 scales weights by 2^8 before the split (include/hrseg.h): a folded weight beyond ~255 (a tiny running
+                # variance under a large gamma) would leave the fp16 range.  Checked ONCE per fold (one readback per layer when
+                # the parameters changed, not per forward); such a layer runs the exact-fp32 kernels.
+                n4 = w_f.numel() // 4 * 4
+                wmax = float(ops.absmax(w_f[:n4].view(1, 1, n4 // 4, 4))) if n4 else 0.0
+                hit = conv._hr_fold = (tok, w_f, b_f, wmax <= 240.0)
+            return hit[1], hit[2], hit[3]
+        return fold
+
+    def notify_parameters_changed(self):
+        """an optimizer (or anyone writing parameters / buffers outside torch's in-place ops) calls this: folded inference
+        weights are rebuilt on the next eval forward"""
+        self._param_epoch += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        self._param_epoch += 1
+        return super().load_state_dict(*args, **kwargs)
 
     def _bn_sync(self):
         """process group for cross-rank BatchNorm statistics, or None (the default: statistics stay per rank)"""

@@ -32,7 +32,7 @@ _f = C.c_float
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
     _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")] + \
-               [("grad_absmax", _p)]
+               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i)]
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "hrseg_bn_stats": [_p, _i, _l, _i, _p, _i, _p],
     "hrseg_bn_finalize": [_p, _i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p],
     "hrseg_bn_eval_coef": [_p, _p, _p, _p, _f, _i, _p, _p],
+    "hrseg_bn_fold": [_p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "hrseg_bn_apply": [_p, _i, _p, _p, _i, _i, _p, _i, _l, _i, _p],
     "hrseg_bn_bwd_reduce": [_p, _i, _p, _i, _i, _p, _i, _p, _l, _i, _p, _i, _p],
     "hrseg_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _l, _i, _i, _p],
@@ -200,7 +201,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 8     # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 9     # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

@@ -151,6 +151,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// BatchNorm (running statistics) folded into the preceding convolution's weights and bias: block = one output channel
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                                      int row, float* __restrict__ w_out, float* __restrict__ b_out) {
+  const int co = blockIdx.x;
+  const float s = (gamma ? gamma[co] : 1.f) / sqrtf(rvar[co] + eps);
+  for (int i = threadIdx.x; i < row; i += 256) w_out[(size_t)co * row + i] = w[(size_t)co * row + i] * s;
+  if (threadIdx.x == 0) b_out[co] = ((bias ? bias[co] : 0.f) - rmean[co]) * s + (beta ? beta[co] : 0.f);
+}
+
 __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                     float eps, int C, float* coef) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -960,6 +971,16 @@ extern "C" int hrseg_bn_finalize(const double* partial, int nchunks, long npix, 
                      npix, C, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
                      coef);
   HRSEG_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
+extern "C" int hrseg_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, int Cout, int row, float* w_out, float* b_out,
+                             hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(w && running_mean && running_var && w_out && b_out && Cout > 0 && row > 0, "hrseg_bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, bias, gamma, beta, running_mean,
+                     running_var, eps, row, w_out, b_out);
+  HRSEG_LAUNCH_CHECK("bn_fold");
   return 0;
 }
 

@@ -89,6 +89,7 @@ static IgemmPlan plan_igemm(const IgemmArgs& a) {
   if (pl.ksplit > nst) pl.ksplit = nst;
   if (pl.ksplit < 1) pl.ksplit = 1;
   if (!(a.accumulate || (a.ldy == a.N && a.oys == 1 && a.oxs == 1))) pl.ksplit = 1;
+  if (a.res || a.relu) pl.ksplit = 1;          // (a fused residual / ReLU epilogue needs the finished sum)
   return pl;
 }
 
@@ -138,6 +139,7 @@ static SpPlan plan_sp(const IgemmArgs& a) {
   if (pl.ksplit > nslabs) pl.ksplit = nslabs;
   if (pl.ksplit < 1) pl.ksplit = 1;
   if (!(a.accumulate || (a.ldy == a.N && a.oys == 1 && a.oxs == 1))) pl.ksplit = 1;
+  if (a.res || a.relu) pl.ksplit = 1;          // (a fused residual / ReLU epilogue needs the finished sum)
   return pl;
 }
 
@@ -576,7 +578,8 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
     tiles[i] = kind[i] ? (int)patch_tiles(fa[i], wtn) : ceil_div(a[i].M, 64 * wtm) * (a[i].N / (16 * wtn));
     const int nstages = ns ? (a[i].ntaps * (a[i].K / 16) + 1) / 2 : a[i].ntaps * (a[i].K / (16 * kc));
     ks[i] = 1;
-    const bool can_split = !kind[i] && (a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1));
+    const bool can_split = !kind[i] && !a[i].res && !a[i].relu &&
+                           (a[i].accumulate || (a[i].ldy == a[i].N && a[i].oys == 1 && a[i].oxs == 1));
     if (can_split && tiles[i] < 512 && !hrseg_g_deterministic) {
       ks[i] = ceil_div(512, tiles[i]);
       const int min_stages = ns ? 8 : 12;        // stages (fp32: 16*kc channels; split precision: 32-channel slabs) per slice
@@ -796,6 +799,7 @@ static int check_shape(const hrseg_conv_shape_t* s, const char* who) {
   HRSEG_CHECK_ARG(ho == s->Ho && wo == s->Wo, "%s: output %dx%d does not match input %dx%d k%d s%d (expect %dx%d)",
                   who, s->Ho, s->Wo, s->Hi, s->Wi, s->ksize, s->stride, ho, wo);
   HRSEG_CHECK_ARG(s->ldx >= s->Cin && s->ldy >= s->Cout, "%s: ld smaller than channel count", who);
+  HRSEG_CHECK_ARG(!s->residual || (s->ldr >= s->Cout && s->ldr % 4 == 0), "%s: residual stride %d (Cout %d)", who, s->ldr, s->Cout);
   HRSEG_CHECK_ARG((long)s->B * s->Hi * s->Wi < (1L << 31) && (long)s->B * s->Ho * s->Wo < (1L << 31),
                   "%s: more than 2^31 pixels per tensor is not supported (32-bit pixel indices)", who);
   return 0;
@@ -825,6 +829,7 @@ static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const fl
   for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
   pack_taps(a, a.T, oy, ox, wt);
   set_sp_scales(a, s->precision, nullptr);
+  a.res = s->residual; a.ldr = s->ldr; a.relu = s->relu;
 }
 
 // stride-1 data gradient as a forward-style gather over dy with the transposed weights
@@ -980,18 +985,8 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   }
   HRSEG_CHECK_ARG(s->Cin % 16 == 0, "hrseg_conv_fwd: Cin %d not a multiple of 16", s->Cin);
   HRSEG_CHECK_ARG(s->ldx % 4 == 0 && s->ldy % 4 == 0, "hrseg_conv_fwd: ld must be a multiple of 4");
-  IgemmArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.y = y; a.ldx = s->ldx; a.ldy = s->ldy;
-  a.B = s->B; a.Hi = s->Hi; a.Wi = s->Wi; a.K = s->Cin;
-  a.Ho = s->Ho; a.Wo = s->Wo; a.N = s->Cout; a.M = s->B * s->Ho * s->Wo;
-  a.sy = a.sx = s->stride;
-  a.Hy = s->Ho; a.Wy = s->Wo; a.oys = a.oxs = 1; a.oy0 = a.ox0 = 0;
-  a.T = s->ksize * s->ksize; a.accumulate = 0;
-  int oy[9], ox[9], wt[9];
-  const int pad = (s->ksize - 1) / 2;
-  for (int t = 0; t < a.T; ++t) { oy[t] = t / s->ksize - pad; ox[t] = t % s->ksize - pad; wt[t] = t; }
-  pack_taps(a, a.T, oy, ox, wt);
-  set_sp_scales(a, s->precision, nullptr);
+  IgemmArgs a;
+  fill_fwd_args(a, x, w, bias, y, s);
   if (int e = dispatch_igemm(a, s->precision, st)) return e;
   HRSEG_LAUNCH_CHECK("igemm_conv(fwd)");
   return 0;

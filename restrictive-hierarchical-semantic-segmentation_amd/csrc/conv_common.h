@@ -29,6 +29,8 @@ struct IgemmArgs {
   float wscale, wscale_inv;  // fp16x2: fixed power-of-two scale of the weight operand and its inverse (1 otherwise)
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
   const unsigned char* wimg; // wave-specialised patch body: pre-split weight image (sp_weight_image_kernel), else null
+  const float* res;          // fused epilogue (inference, BatchNorm folded into w / bias): y = relu?(conv + bias + res[pixel][channel])
+  int ldr, relu;             //   res may be null; both are ignored by split-K launches (the planners keep ksplit = 1 when set)
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for

@@ -195,6 +195,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& p, float* lds, const
         for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
       } else {
         if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + ch);
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         *reinterpret_cast<f32x4*>(yrow + ch) = v;
       }
     }

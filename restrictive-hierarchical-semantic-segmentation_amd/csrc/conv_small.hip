@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ y, int ldy, int B, int Hi,
                                                                  int Wi, int Cin, int Ho, int Wo, int Cout,
-                                                                 int ks, int stride) {
+                                                                 int ks, int stride, const float* __restrict__ res, int ldr,
+                                                                 int relu) {
   __shared__ float wl[64 * 9 * CMAX];
   const int T = ks * ks, pad = (ks - 1) / 2;
   const int cb = blockIdx.y * 64;  // channel block
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int co = cb + cg * 16 + j;
-    if (co < Cout) yp[j] = acc[j] + (bias ? bias[co] : 0.f);
+    if (co < Cout) {
+      float v = acc[j] + (bias ? bias[co] : 0.f);
+      if (res) v += res[(size_t)m * ldr + co];
+      yp[j] = relu ? fmaxf(v, 0.f) : v;
+    }
   }
 }
 
@@ -188,14 +193,16 @@ __global__ __launch_bounds__(256) void conv_small_cin_dgrad_kernel(const float* 
 }
 
 void launch_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, const hrseg_conv_shape_t* s, hipStream_t st) {
+  const float* res = s->residual;
+  const int ldr = s->ldr, relu = s->relu;
   const long M = (long)s->B * s->Ho * s->Wo;
   dim3 grid(ceil_div(M, 64), ceil_div(s->Cout, 64));
   if (s->Cin <= 4)
     hipLaunchKernelGGL(conv_small_cin_fwd_kernel<4>, grid, dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B, s->Hi, s->Wi,
-                       s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride);
+                       s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, res, ldr, relu);
   else
     hipLaunchKernelGGL(conv_small_cin_fwd_kernel<8>, grid, dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B, s->Hi, s->Wi,
-                       s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride);
+                       s->Cin, s->Ho, s->Wo, s->Cout, s->ksize, s->stride, res, ldr, relu);
 }
 void launch_small_cin_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s, int ppb, hipStream_t st) {
   const long M = (long)s->B * s->Ho * s->Wo;

@@ -373,6 +373,10 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
 #pragma unroll
       for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrows[m] + n0 + 16 * n + 4 * g);
     }
+    if (p.res && !split) {
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n0 + 16 * n + 4 * g);
+    }
   }
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
@@ -388,6 +392,10 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
       } else {
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         *reinterpret_cast<f32x4*>(yrow + ch) = v;
       }
     }
@@ -692,6 +700,11 @@ __device__ __forceinline__ void igemm_spw_body(const IgemmArgs& p, unsigned char
         for (int e = 0; e < 4; ++e) atomicAdd(yrow + ch + e, v[e]);
       } else {
         if (p.accumulate) v += *reinterpret_cast<const f32x4*>(yrow + ch);
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + ch);
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         *reinterpret_cast<f32x4*>(yrow + ch) = v;
       }
     }
@@ -1111,6 +1124,16 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
         for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.n0 + 16 * n + 4 * g);
       }
     }
+    if (p.res) {
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) {
+        const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+        if (oy >= H || ox >= W) continue;
+        const float* rrow = p.res + ((size_t)(q.b * H + oy) * W + ox) * p.ldr;
+#pragma unroll
+        for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(rrow + q.n0 + 16 * n + 4 * g);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
       const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
@@ -1120,7 +1143,12 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
       for (int n = 0; n < WTN; ++n) {
         f32x4 v = acc[n][m];
         if (NS == 4) v *= oscale;
-        *reinterpret_cast<f32x4*>(yrow + q.n0 + 16 * n + 4 * g) = v + add[m][n];
+        v += add[m][n];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(yrow + q.n0 + 16 * n + 4 * g) = v;
       }
     }
   };
@@ -1374,14 +1402,30 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g);
         }
       }
+      if (p.res) {
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) {
+          const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
+          if (oy >= H || ox >= W) continue;
+          const float* rrow = p.res + ((size_t)(q.b * H + oy) * W + ox) * p.ldr;
+#pragma unroll
+          for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(rrow + q.nt * BN + 16 * n + 4 * g);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m, ox = q.x0 + r16;
         if (oy >= H || ox >= W) continue;
         float* yrow = p.y + ((size_t)(q.b * H + oy) * W + ox) * p.ldy;
 #pragma unroll
-        for (int n = 0; n < WTN; ++n)
-          *reinterpret_cast<f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g) = acc[n][m] * oscale + add[m][n];
+        for (int n = 0; n < WTN; ++n) {
+          f32x4 v = acc[n][m] * oscale + add[m][n];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g) = v;
+        }
       }
     };
     bf16x8 xfr[2][RPW][NP], wfr[2][WTN][NP];

@@ -159,7 +159,8 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0, sync=None):
+    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0, sync=None, fold=None):
+        self.fold = fold                 # inference: (conv, bn) -> (folded weight, folded bias), or None = BN as its own launches
         self.sync = sync                 # process group for cross-rank BatchNorm statistics (opt-in sync_bn), else None
         self.prec = prec                 # _lib.CONV_PRECISION code of every convolution of this forward (and its backward)
         self.training = training
@@ -223,6 +224,21 @@ class Recorder:
         k, s = items[0][1].kernel_size[0], items[0][1].stride[0]
         assert all(c.kernel_size[0] == k and c.stride[0] == s for _, c, _, _ in items)
         xs = [it[0] for it in items]
+        if not self.training and not self.record and self.fold is not None:
+            # inference: BatchNorm folded into the weights (cached per conv until a parameter or a running statistic
+            # changes), residual add and ReLU in the convolution's epilogue: ONE launch per layer group
+            folded = [self.fold(conv, bn) for _, conv, bn, _ in items]
+            res = [it[3].data if it[3] is not None else None for it in items]
+            prec = self.prec if all(f[2] for f in folded) else _lib.CONV_PRECISION["f32"]    # (a folded weight out of fp16x2's range)
+            if n == 1:
+                conv = items[0][1]
+                zs = [ops.conv_fwd(xs[0].data, folded[0][0], folded[0][1], k, s, cout=conv.out_channels, prec=prec,
+                                   residual=res[0], relu=relus[0], out=outs[0] if outs is not None else None)]
+            else:
+                assert outs is None or all(o is None for o in outs)
+                zs = ops.conv_fwd_group([x.data for x in xs], [f[0] for f in folded], [f[1] for f in folded], k, s,
+                                        [c.out_channels for _, c, _, _ in items], prec=prec, residuals=res, relus=relus)
+            return [Act(z) for z in zs]
         if n == 1:
             conv = items[0][1]
             ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,

@@ -68,11 +68,13 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None):
-    """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h"""
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False):
+    """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h;
+    residual / relu: the forward's fused epilogue y = relu?(conv + bias + residual) (inference with folded BatchNorm)"""
     B, Hi, Wi, Cin = x_shape
     return ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
-                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec, grad_absmax=ptr(gmax))
+                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec, grad_absmax=ptr(gmax),
+                     residual=ptr(residual), ldr=_ld(residual) if residual is not None else 0, relu=int(bool(relu)))
 
 
 # ------------------------------------------------------------------ convolution
@@ -103,7 +105,7 @@ def _guard_prec(x, prec):
 range_fallbacks = 0
 
 
-def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
+def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
     pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions)."""
     _lib.ensure_scratch(x.device)
@@ -112,7 +114,7 @@ def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0):
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
-    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec)
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu)
     call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
     return out
 
@@ -142,17 +144,19 @@ def _shape_array(shapes):
     return (ConvShape * len(shapes))(*shapes)
 
 
-def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0):
-    """n independent convolutions (same k, s) in one launch when the library can group them"""
+def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None):
+    """n independent convolutions (same k, s) in one launch when the library can group them; residuals / relus: the fused
+    epilogue per problem (inference with folded BatchNorm)"""
     _lib.ensure_scratch(xs[0].device)
     if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
         prec = _lib.CONV_PRECISION["f32"]        # (one precision per grouped call)
     outs, shapes = [], []
-    for x, co in zip(xs, couts):
+    for i, (x, co) in enumerate(zip(xs, couts)):
         B, Hi, Wi, Cin = x.shape
         y = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), co, x)
         outs.append(y)
-        shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec))
+        shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec, residual=residuals[i] if residuals is not None else None,
+                             relu=relus[i] if relus is not None else False))
     has_bias = any(b is not None for b in biases)
     call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
          _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
@@ -215,6 +219,16 @@ def bn_train_coef(y, gamma, beta, running_mean, running_var, nbt, momentum, eps)
     call("hrseg_bn_finalize", ptr(part), nch, npix, Cn, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(nbt), float(momentum), float(eps), ptr(coef))
     return coef
+
+
+def bn_fold(w, bias, gamma, beta, running_mean, running_var, eps, cout):
+    """BatchNorm (running statistics) folded into the convolution in front of it -> (folded weight [same storage layout],
+    folded bias [Cout]); hrseg_bn_fold"""
+    w_f = torch.empty_like(w)
+    b_f = torch.empty(cout, dtype=torch.float32, device=w.device)
+    call("hrseg_bn_fold", ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), cout,
+         w.numel() // cout, ptr(w_f), ptr(b_f))
+    return w_f, b_f
 
 
 def bn_eval_coef(gamma, beta, running_mean, running_var, eps):

@@ -65,6 +65,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._sync_hyper(flat.data.device)
         self._step += 1
         ops.adamw_dev(flat.data, flat.grad, self._m, self._v, self._hyper, self._state)
+        if hasattr(self.model, "notify_parameters_changed"):
+            self.model.notify_parameters_changed()
 
     def zero_grad(self, set_to_none=True):
         flat = self.model._flat

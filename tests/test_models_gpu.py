@@ -11,6 +11,8 @@ from tests.helpers import CASES, CONV_MODES, build_model, conv_mode, level_weigh
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+_ORACLE_STEPS = {}       # golden case -> (the CPU oracle's two train steps, its state_dict after them)
+_ORACLE_RAGGED = {}
 
 
 def _args(kind, hier, num_classes, weights, batch):
@@ -121,8 +123,14 @@ def test_train_steps_track_the_oracle(name, mode):
     args = _args(kind, hier, num_classes, weights, batch)
     x, target = torch.from_numpy(g["x"]), torch.from_numpy(g["target"])
 
-    om = build_model(OM, kind, hier, tree, size)
-    oopt = torch.optim.AdamW(om.parameters(), lr=1e-4)
+    if name not in _ORACLE_STEPS:          # the oracle's two steps do not depend on the product's convolution mode: run once
+        om = build_model(OM, kind, hier, tree, size)
+        oopt = torch.optim.AdamW(om.parameters(), lr=1e-4)
+        refs = [OT.train_step(om, oopt, x, target, num_classes, weights, hierarchical=hier, is_unet=(kind == "unet"))
+                for _ in range(2)]
+        refs = [dict(loss=r["loss"].detach().clone(), metrics={k: np.array(v) for k, v in r["metrics"].items()}) for r in refs]
+        _ORACLE_STEPS[name] = (refs, {n: v.detach().clone() for n, v in om.state_dict().items()})
+    refs, osd = _ORACLE_STEPS[name]
     pm = build_model(PM, kind, hier, tree, size).cuda()
     popt = PT.FusedAdamW(pm, lr=[1e-4])
     loss_fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in num_classes]
@@ -130,7 +138,7 @@ def test_train_steps_track_the_oracle(name, mode):
     level_loss = []
     with conv_mode(pm, mode) as cm_ctx:
         for step in range(2):
-            ref = OT.train_step(om, oopt, x, target, num_classes, weights, hierarchical=hier, is_unet=(kind == "unet"))
+            ref = refs[step]
             loss, cms = PT.train_step(pm, popt, x.cuda(), target.cuda(), loss_fns, args, tree, level_loss)
             assert abs(float(loss) - ref["loss"].item()) < TOL * abs(ref["loss"].item()), f"step {step}"
             vec = PT._metric_vectors(cms)
@@ -146,7 +154,6 @@ def test_train_steps_track_the_oracle(name, mode):
                     assert np.allclose(got, v, atol=5e-2) and np.abs(got - v).mean() < 1e-2, (step, k, got, v)
     cm_ctx.check_families(kind)
     # parameters after two AdamW steps
-    osd = om.state_dict()
     for n, p in pm.state_dict().items():
         a, b = p.detach().cpu().double(), osd[n].double()
         if n.endswith("num_batches_tracked"):
@@ -607,10 +614,19 @@ def test_ragged_shapes_against_the_oracle(kind, H, W, B, mode):
     x = torch.from_numpy(g.standard_normal((B, 3, H, W)).astype(np.float32))
     lab = g.integers(0, 7, size=(B, H, W))
     target = torch.from_numpy(synth.encode_targets(lab, tree, True))
-    om = build_model(OM, kind, True, tree, max(H, W))
+    key = (kind, H, W, B)
+    if key not in _ORACLE_RAGGED:          # the oracle's passes do not depend on the product's convolution mode: run once
+        om = build_model(OM, kind, True, tree, max(H, W))
+        om.train()
+        with torch.no_grad():
+            _, zo = om(x, type=1) if kind == "unet" else om(x)
+        om.eval()
+        with torch.no_grad():
+            _, ze = om(x, type=1) if kind == "unet" else om(x)
+        _ORACLE_RAGGED[key] = ([z.clone() for z in zo], [z.clone() for z in ze])
+    zo, zo_eval = _ORACLE_RAGGED[key]
     pm = build_model(PM, kind, True, tree, max(H, W)).cuda()
-    om.train(), pm.train()
-    _, zo = om(x, type=1) if kind == "unet" else om(x)
+    pm.train()
     with conv_mode(pm, mode) as cm_ctx:
         _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
     if mode in ("fp16x2", "auto_ws"):
@@ -625,12 +641,11 @@ def test_ragged_shapes_against_the_oracle(kind, H, W, B, mode):
         ce, dice = PL.fused_ce_dice(b, t.cuda(), weights[L])[:2]
         lp = lp + ce
     assert abs(float(lp) - float(lo)) < TOL * max(1.0, abs(float(lo)))
-    om.eval(), pm.eval()
+    pm.eval()
     with torch.no_grad():
-        _, zo = om(x, type=1) if kind == "unet" else om(x)
         with conv_mode(pm, mode):
             _, zp = pm(x.cuda(), type=1) if kind == "unet" else pm(x.cuda())
-    for L, (a, b) in enumerate(zip(zo, zp)):
+    for L, (a, b) in enumerate(zip(zo_eval, zp)):
         assert rel_err(b.cpu().numpy(), a.numpy()) < TOL, f"eval logits {L}"
 
 

@@ -154,3 +154,56 @@ def test_predict_loop_matches_the_oracle(kind, hier, tmp_path):
     assert rows[0] == ["Type", "Class", "Accuracy", "IoU", "Dice", "Precision", "Recall"]
     assert rows[1][:2] == ["Average", "All"] and abs(float(rows[1][3]) - out["iou"]) < 1e-6
     assert len(rows) == 2 + sum(nc_full) and rows[2][:2] == ["Class", "0"]
+
+
+@pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64", "hrnet_flat_tl_64"])
+def test_inference_with_folded_batchnorm_matches_the_goldens_and_the_unfolded_path(name):
+    """eval-mode forward with BatchNorm folded into the convolution weights and residual + ReLU in the convolution epilogue
+    (hrseg_bn_fold, hrseg_conv_shape_t.residual / relu; reference ops models.py:113-118, 332-354 in eval mode): the
+    reference-generated eval logits at 1e-3, the unfolded three-launch path at 1e-5, the fold cache invalidated by an
+    optimizer step and by load_state_dict, and a folded weight outside fp16x2's range routed to the exact-fp32 kernels"""
+    from hrseg_amd import _lib, train as PT
+    from hrseg_amd.Models import models as PM
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    x = torch.from_numpy(g["x"]).cuda()
+    nc = [int(v) for v in g["num_classes"]]
+    args = argparse.Namespace(model_type=1 if hier else 0, model_select=0 if kind == "unet" else 1, num_classes=nc)
+    model = build_model(PM, kind, hier, tree, size).cuda()
+    model.eval()
+
+    def logits(fold):
+        model.fold_bn = fold
+        with torch.no_grad():
+            _, z = PT._model_call(model, x, args, tree)
+        return z if hier else [z]
+    folded, plain = logits(True), logits(False)
+    for L, (a, b) in enumerate(zip(folded, plain)):
+        assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max()), L
+        ref = g[f"eval_logits{L}"]
+        assert float(np.abs(a.cpu().numpy() - ref).max()) < 1e-3 * float(np.abs(ref).max()), L
+    # the cache: a second forward folds nothing; a parameter change refolds
+    first = next(m for m in model.modules() if hasattr(m, "_hr_fold"))
+    tok = first._hr_fold[0]
+    logits(True)
+    assert first._hr_fold[0] == tok
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    key = next(k for k in sd if k.endswith("running_var"))
+    sd[key] = sd[key] * 4.0
+    model.load_state_dict(sd)
+    changed = logits(True)
+    assert first._hr_fold[0] != tok
+    again_plain = logits(False)
+    for a, b in zip(changed, again_plain):
+        assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+    assert float((changed[0] - folded[0]).abs().max()) > 0
+    # a folded weight beyond fp16x2's weight range: the layer runs the exact-fp32 kernels, results stay finite and right
+    with torch.no_grad():
+        bn = next(m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        bn.running_var.fill_(1e-9)
+        bn.weight.mul_(50.0)
+    model.notify_parameters_changed()
+    hot, hot_plain = logits(True), logits(False)
+    for a, b in zip(hot, hot_plain):
+        assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 1e-4 * float(b.abs().max())
