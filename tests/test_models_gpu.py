@@ -651,7 +651,7 @@ def test_ragged_shapes_against_the_oracle(kind, H, W, B, mode):
 
 # ---------------------------------------------------------------------------------------------------------------
 # SURVEY 8(f4) opt-in extensions (default off; the reference has none of them in running code)
-@pytest.mark.parametrize("kind,size", [("unet", 64), ("hrnet", 128)])
+@pytest.mark.parametrize("kind,size", [("unet", 64), ("hrnet", 64)])
 def test_concat_prev_logits_against_the_oracle(kind, size):
     """logit-concatenated re-encoding (north_star wording; models.py:267,277 is where the reference re-runs on the image
     only): level L >= 1 encodes cat(image, logits_{L-1}) through its own first convolution.  Train-mode logits, loss,
