@@ -682,6 +682,7 @@ __device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nbl
 struct BnFwdG { BnGroupHdr h; hrseg_bn_fwd_t p[BN_MAXG]; };
 struct BnBwdG { BnGroupHdr h; hrseg_bn_bwd_t p[BN_MAXG]; };
 
+template <bool MASK>
 __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0, const float* __restrict__ zmask,
                                            int ldz, int relu, const float* __restrict__ yy, int ldy,
                                            const float* __restrict__ coef, long npix, int C,
@@ -711,8 +712,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
     constexpr int U = 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long pix0 = lo + L.pl; pix0 < hi; pix0 += (long)U * L.P) {
-      f32x4 v[U], yv[U], zz[U];
-      unsigned bm[U];
+      f32x4 v[U], yv[U], zz[U];      // (zz[u][0] carries the mask byte when the layer has one)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long pix = pix0 + (long)u * L.P;
@@ -720,7 +720,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
         v[u] = ok ? ld4(a0 + pix * ld0 + 4 * L.cq) : zero;
         if (bwd) {
           yv[u] = ok ? ld4(yy + pix * ldy + 4 * L.cq) : mean;
-          if (relu && bmask) bm[u] = ok ? bmask[pix * L.Q + L.cq] : 0u;
+          if (MASK && relu && bmask) zz[u][0] = __uint_as_float(ok ? (unsigned)bmask[pix * L.Q + L.cq] : 0u);
           else if (relu && zmask) zz[u] = ok ? ld4(zmask + pix * ldz + 4 * L.cq) : zero;
         }
       }
@@ -731,9 +731,10 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
           s2 += v[u] * v[u];
         } else {
           f32x4 gv = v[u];
-          if (relu && bmask) {
+          if (MASK && relu && bmask) {
+            const unsigned bm = __float_as_uint(zz[u][0]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gv[j] = ((bm[u] >> j) & 1u) ? gv[j] : 0.f;
+            for (int j = 0; j < 4; ++j) gv[j] = ((bm >> j) & 1u) ? gv[j] : 0.f;
           } else if (relu) {
             // z not given: the forward had no residual, so z > 0 <=> y*scale+shift > 0 (4 bytes less per element)
             const f32x4 zc = zmask ? zz[u] : bn_affine(yv[u], sc, sh);
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256) void bn_stats_group_kernel(BnFwdG g) {
   __shared__ double red[256 * 8];
   int local, nblk;
   const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
-  stats_body(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1);
+  stats_body<false>(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
@@ -851,6 +852,10 @@ __global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
   }
 }
 
+// MASK = some problem of the launch brings ReLU mask bytes.  Two instances because of REGISTERS: beside the 64-channel
+// nine-tap weight gradient of the side stream (394 registers per lane of a SIMD) a wave of this kernel only fits under 112;
+// the mask path costs 11 more (118) -- with one instance the UNet step, which has no masked layer at all, lost 2 ms of overlap.
+template <bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   __shared__ double red[256 * 8];
   int local, nblk;
@@ -858,8 +863,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   // the |dy| slots the apply kernel raises with atomicMax start from zero: reset here, two launches earlier on the stream
   if (local == 0 && threadIdx.x < 64 && p.dy_absmax) p.dy_absmax[threadIdx.x] = 0.f;
-  stats_body(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
-             nseg, p.relu_mask);
+  stats_body<MASK>(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
+                   nseg, p.relu_mask);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
@@ -1300,7 +1305,10 @@ extern "C" int hrseg_bn_bwd_group_phases(int n, const hrseg_bn_bwd_t* probs, int
   int end = 0;
   if (phases & 1) {
     for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-    hipLaunchKernelGGL(bn_bwd_reduce_group_kernel, dim3(end), dim3(256), 0, st, g);
+    bool masked = false;
+    for (int i = 0; i < n; ++i) masked = masked || (probs[i].relu && probs[i].relu_mask);
+    if (masked) hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<true>, dim3(end), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<false>, dim3(end), dim3(256), 0, st, g);
     HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
   }
   if (phases & 2) {
