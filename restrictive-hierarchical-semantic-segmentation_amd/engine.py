@@ -30,6 +30,7 @@ _SIDE = {}
 
 
 _SIDE_ENABLED = None
+_WGRAD_ORDER = os.environ.get("HRSEG_WGRAD_ORDER", "before")
 _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the backward of residual layers reads z for its ReLU mask
 
 
@@ -289,23 +290,30 @@ class Recorder:
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments,
                                dy_absmax=gmaxs[i]))
             dys = ops.bn_bwd_group(bw, eval_mode, sync=self.sync)
-            side = wgrad_stream(dys[0].device)
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                if n == 1:
-                    ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0])
-                else:
-                    ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
-                                         prec=self.prec, gmaxs=gmaxs)
-            if side is not None:
-                if gmax_all is not None:
-                    gmax_all.record_stream(side)
-                for t in dys:
-                    t.record_stream(side)     # not reused before the side stream is done reading it
-                for x in xs:
-                    x.data.record_stream(side)
-                self.used_side = True
+            # order of the two gradients (HRSEG_WGRAD_ORDER): "after" = the weight gradient is issued on the side stream BEHIND
+            # the data gradient of the same layer, so that it runs beside the BatchNorm backward of the NEXT (earlier) layer --
+            # an MFMA-bound kernel next to bandwidth-bound ones -- instead of beside its own data gradient (two MFMA-bound
+            # kernels sharing the CUs gain nothing); "before" = round-2 order
+            def weight_gradients():
+                side = wgrad_stream(dys[0].device)
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    if n == 1:
+                        ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0])
+                    else:
+                        ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
+                                             prec=self.prec, gmaxs=gmaxs)
+                if side is not None:
+                    if gmax_all is not None:
+                        gmax_all.record_stream(side)
+                    for t in dys:
+                        t.record_stream(side)     # not reused before the side stream is done reading it
+                    for x in xs:
+                        x.data.record_stream(side)
+                    self.used_side = True
+            if _WGRAD_ORDER != "after":
+                weight_gradients()
             # data gradients: rounds of problems whose inputs are distinct tensors
             todo = [i for i, x in enumerate(xs) if x.needs_grad]
             while todo:
@@ -330,6 +338,8 @@ class Recorder:
                     for i, o in zip(rnd, got):
                         xs[i].grad = o
                 todo = rest
+            if _WGRAD_ORDER == "after":
+                weight_gradients()
         self._push(bwd)
         return zs
 
