@@ -32,14 +32,15 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
   for (int i = 0; i < CNT_N; ++i)
-    if (!family || !strcmp(family, g_cnt_names[i])) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+    if (family ? !strcmp(family, g_cnt_names[i]) : i != CNT_WS_CANVAS) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+  if (!family && reset) g_cnt[CNT_WS_CANVAS] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
   return total;
 }
 
@@ -231,11 +232,32 @@ static unsigned char* scratch_reserve(hipStream_t st, size_t bytes) {
 // 8 x 16 pixel tiles, 2 = 96 x 48, 3 = 64 x 64, 4 = 48 x 48 on 16 x 16 pixel tiles (a 48-channel slab on 8 rows is
 // 18 MFMAs per wave: too short for the producers to keep up)
 static const int WS_WTN[5] = {0, 3, 6, 4, 3}, WS_CS[5] = {0, 3, 3, 4, 3}, WS_TH[5] = {0, 8, 8, 8, 16};
+// Canvas mode of the wave-specialised body (conv_sp.h): the images of the batch side by side with a zero column between
+// them, tiled as ONE image.  Taken when it cuts the padded area by at least 5 % (39 x 39: 1.26x -> 1.05x, 20 x 20: 1.92x ->
+// 1.32x at 8 images; the 155 / 78-pixel branches stay per image) and the multiply-high image lookup is exact.
+static int g_ws_canvas = 1;             // hrseg_tune "sp_ws_canvas": 0 = per-image tiles everywhere
+static long ws_pixel_tiles(const IgemmArgs& a, int kind, bool canvas) {       // 16-column x TH-row tiles of the whole batch
+  const long ty = ceil_div(a.Ho, WS_TH[kind]);
+  return canvas ? ty * ceil_div((long)a.B * (a.Wo + 1) - 1, 16) : (long)a.B * ty * ceil_div(a.Wo, 16);
+}
+static bool ws_canvas(const IgemmArgs& a, int kind) {
+  if (!g_ws_canvas || a.B < 2 || (long)a.B * (a.Wo + 1) >= 65536) return false;
+  if ((long)a.B * a.Ho * a.Wo * a.ldx * 4 >= (1l << 31)) return false;          // one buffer descriptor spans the batch
+  return ws_pixel_tiles(a, kind, true) * 100 <= ws_pixel_tiles(a, kind, false) * 95;
+}
 static long ws_tiles(const IgemmArgs& a, int kind) {
-  return (long)a.B * ceil_div(a.Ho, WS_TH[kind]) * ceil_div(a.Wo, 16) * (a.N / (16 * WS_WTN[kind]));
+  return ws_pixel_tiles(a, kind, ws_canvas(a, kind)) * (a.N / (16 * WS_WTN[kind]));
 }
 static double ws_waste(const IgemmArgs& a, int kind) {
-  return (double)(ceil_div(a.Ho, WS_TH[kind]) * WS_TH[kind]) * (ceil_div(a.Wo, 16) * 16) / ((double)a.Ho * a.Wo);
+  return (double)ws_pixel_tiles(a, kind, ws_canvas(a, kind)) * WS_TH[kind] * 16 / ((double)a.B * a.Ho * a.Wo);
+}
+static void ws_set_canvas(IgemmArgs& a, int kind) {
+  a.cv_w1 = a.cv_nb = 0;
+  a.cv_magic = 0u;
+  if (!ws_canvas(a, kind)) return;
+  a.cv_w1 = a.Wo + 1;
+  a.cv_nb = a.B;
+  a.cv_magic = (unsigned)(((1ull << 32) + a.cv_w1 - 1) / a.cv_w1);
 }
 static int ws_kind(const IgemmArgs& a) {
   if (!g_sp_ws || !scratch_usable() || patch_flip(a) < 0 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
@@ -243,9 +265,10 @@ static int ws_kind(const IgemmArgs& a) {
   if (a.oy_min != -1 || a.ox_min != -1) return 0;
   int kind = (a.K % 48 == 0 && a.N % 48 == 0) ? 1 : (a.K % 64 == 0 && a.N % 64 == 0) ? 3 : 0;
   if (!kind) return 0;
-  if (kind == 1) {
-    if (a.N % 96 == 0 && ws_tiles(a, 2) >= 160) kind = 2;
-    else if (ws_waste(a, 4) <= 1.10 && ws_tiles(a, 4) >= 256) kind = 4;
+  if (kind == 1) {      // the tiling is chosen on the per-image tile counts (a size class of the problem), canvas or not
+    auto plain_tiles = [&](int k) { return ws_pixel_tiles(a, k, false) * (a.N / (16 * WS_WTN[k])); };
+    if (a.N % 96 == 0 && plain_tiles(2) >= 160) kind = 2;
+    else if (ws_pixel_tiles(a, 4, false) * 256 <= 1.10 * a.B * a.Ho * a.Wo && plain_tiles(4) >= 256) kind = 4;
   }
   if (ws_waste(a, kind) * 100 > g_ws_waste) return 0;
   if ((kind == 1 || kind == 4) && !g_ws_n48) return 0;
@@ -283,12 +306,14 @@ static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   return true;
 }
 static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
+  ws_set_canvas(a, kind);
   const int ntotal = (int)ws_tiles(a, kind);
   if (!ws_make_images(&a, &kind, 1, st)) return 1;
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
   ++g_cnt[CNT_WS];
+  g_cnt[CNT_WS_CANVAS] += a.cv_w1 > 0;
   return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st);
 }
 // One launch for several problems: the 256 persistent blocks are divided among the problems in proportion to their
@@ -303,6 +328,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     if (flip >= 0 && f != flip) return 1;
     flip = f;
     const int cs = WS_CS[kinds[i]];
+    ws_set_canvas(a[i], kinds[i]);
     ntot[i] = ws_tiles(a[i], kinds[i]);
     cost[i] = (long)(a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
     total += ntot[i] * cost[i];
@@ -337,6 +363,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     g.blk_end[i] = end;
     g.kind[i] = kinds[i];
     g.a[i] = a[i];
+    g_cnt[CNT_WS_CANVAS] += a[i].cv_w1 > 0;
   }
   ++g_cnt[CNT_WS_GROUP];
   return launch_ws_group_kernel(g, flip, st);
@@ -1149,7 +1176,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -29,6 +29,8 @@ struct IgemmArgs {
   float wscale, wscale_inv;  // fp16x2: fixed power-of-two scale of the weight operand and its inverse (1 otherwise)
   int oy_min, ox_min;        // smallest tap offsets (<= 0 for padded convs): the split-precision body bases its descriptor there
   const unsigned char* wimg; // wave-specialised patch body: pre-split weight image (sp_weight_image_kernel), else null
+  int cv_w1, cv_nb;          // wave-specialised body, canvas mode: image pitch on the canvas (W + 1; 0 = plain per-image tiling), images
+  unsigned cv_magic;         //   ceil(2^32 / cv_w1): canvas column -> image by multiply-high
   const float* res;          // fused epilogue (inference, BatchNorm folded into w / bias): y = relu?(conv + bias + res[pixel][channel])
   int ldr, relu;             //   res may be null; both are ignored by split-K launches (the planners keep ksplit = 1 when set)
 };

@@ -95,6 +95,66 @@ def test_ws_conv_bit_identical_to_block_synchronous_kernel_and_close_to_torch(ca
     assert _rel((acc - base).permute(0, 3, 1, 2), xr.grad) < 2 * TOL
 
 
+# Cin, Cout, H, W, B, n48: small images, where the batch is tiled as ONE canvas (images side by side, a zero column between)
+CANVAS_CASES = [
+    (192, 192, 39, 39, 8, 0),     # the third HRNet branch at the headline size: 1.26x -> 1.05x padded area
+    (384, 384, 20, 20, 8, 0),     # the fourth: 1.92x -> 1.32x
+    (64, 64, 20, 23, 3, 0),       # an image boundary inside a tile, odd batch
+    (128, 64, 33, 13, 16, 0),     # pitch 14: every tile straddles an image boundary
+    (64, 128, 9, 7, 11, 0),       # pitch 8: two images per tile, ragged last tile
+    (96, 48, 17, 9, 13, 1),       # 48-channel tiles, two K stages
+    (48, 48, 39, 39, 2, 1),       # two images
+]
+
+
+@pytest.mark.parametrize("case", CANVAS_CASES)
+def test_ws_canvas_tiling_bit_identical_to_per_image_tiling(case):
+    """canvas mode changes which tile computes a pixel, never the products or their order: forward (with bias, residual and
+    ReLU in the epilogue), data gradient and accumulating data gradient must equal the per-image tiling bit for bit, and the
+    fp32 torch-CPU convolution within the fp16x2 tolerance; the launch counter proves the canvas layout was taken"""
+    from hrseg_amd import _lib, ops
+    cin, cout, H, W, B, n48 = case
+    _lib.tune(sp_ws_n48=n48, sp_ws_waste=1000, sp_ws_min_tiles=1)
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, bias, stride=1, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd, wd, dyd, bd, rd = _nhwc(x), w.permute(0, 2, 3, 1).contiguous().cuda().reshape(cout, 9, cin), _nhwc(dy), bias.cuda(), _nhwc(res)
+    wt = ops.weight_transpose(wd, cout, 9, cin)
+    gmax = dyd.abs().max().reshape(1).repeat(64)
+    base = torch.randn(xd.shape, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run():
+        _lib.launch_count(None, reset=True)
+        y = ops.conv_fwd(xd, wd, bd, 3, 1, prec=pr)
+        yr = ops.conv_fwd(xd, wd, bd, 3, 1, prec=pr, residual=rd, relu=True)
+        dx = ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, prec=pr, gmax=gmax)
+        acc = ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, out=base.clone(), accumulate=True, prec=pr, gmax=gmax)
+        return (y, yr, dx, acc), _lib.launch_count("ws"), _lib.launch_count("ws_canvas")
+
+    try:
+        _lib.tune(sp_ws_canvas=1)
+        on, n_ws, n_cv = run()
+        assert n_ws == 4 and n_cv == 4, (n_ws, n_cv)
+        _lib.tune(sp_ws_canvas=0)
+        off, n_ws, n_cv = run()
+        assert n_ws == 4 and n_cv == 0, (n_ws, n_cv)
+    finally:
+        _lib.tune(sp_ws_canvas=1, sp_ws_waste=200, sp_ws_min_tiles=0)
+    for a, b, what in zip(on, off, ("forward", "forward + residual + relu", "data gradient", "accumulating data gradient")):
+        assert torch.equal(a, b), f"{what}: canvas and per-image tilings differ"
+    assert _rel(on[0].permute(0, 3, 1, 2), y_ref) < TOL
+    assert _rel(on[1].permute(0, 3, 1, 2), torch.relu(y_ref.detach() + res)) < TOL
+    assert _rel(on[2].permute(0, 3, 1, 2), xr.grad) < TOL
+    assert _rel((on[3] - base).permute(0, 3, 1, 2), xr.grad) < 2 * TOL
+
+
 def _branches(B, seed=5):
     g = torch.Generator().manual_seed(seed)
     chans, sizes = [48, 96, 192, 384], [155, 78, 39, 20]
