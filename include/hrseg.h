@@ -195,7 +195,8 @@ int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int 
                        long npix, int C, int eval_mode, hrseg_stream_t stream);
 
 /* Grouped forms: n (1..8) independent BatchNorm problems in three launches (statistics, finalize,
- * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward. */
+ * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward -- two each when
+ * the caller provides the `acc` accumulators (statistics + finalize, reduce + finalize fused). */
 typedef struct {
   const float* y; int ldy; long npix; int C;       /* conv output [npix][C]                      */
   const float* gamma; const float* beta;
@@ -221,6 +222,17 @@ typedef struct {
                                                         equal shards between the statistics and the finalize
                                                         phase, so the statistics cover stat_ranks*npix pixels
                                                         (0 or 1 = this rank only, the reference's behaviour)  */
+  double* acc;                                       /* optional, training: 16*2*C + 1 doubles that are ZERO on entry
+                                                        (the caller zeroes them once; every call leaves them zero).
+                                                        Given for every problem of a call that runs statistics and
+                                                        finalize together (phases 3 or 7, stat_ranks <= 1), and not
+                                                        in deterministic mode, the two are ONE launch: the blocks
+                                                        add their sums into 16 accumulator rows and the block that
+                                                        arrives last finishes the layer.  The order of those adds
+                                                        is not fixed (last bits of the fp64 sums vary run to run).
+                                                        Measured slower than the three launches on the train steps
+                                                        of this repo (bn_elem.hip); the Python side passes it only
+                                                        on request                                                 */
 } hrseg_bn_fwd_t;
 int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
 /* the same in phases (bit 0 statistics, bit 1 finalize / eval coefficients, bit 2 apply; 7 = all): a caller that
@@ -251,6 +263,9 @@ typedef struct {
                                                         phase; the finalize divides them by it, so that the batch
                                                         means are global and dgamma / dbeta receive this rank's
                                                         share (0 or 1 = this rank only)                      */
+  double* acc;                                       /* optional: 16*max(nseg,1)*2*C + 1 doubles, ZERO on entry and
+                                                        left zero; reduce and finalize in one launch, as for
+                                                        hrseg_bn_fwd_t.acc (`partial` still receives the totals)   */
 } hrseg_bn_bwd_t;
 int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* problems, int eval_mode, hrseg_stream_t stream);
 /* phases: bit 0 reduce, bit 1 finalize, bit 2 apply (7 = all), see hrseg_bn_fwd_group_phases */
