@@ -386,6 +386,14 @@ int hrseg_group_kl(const float* z, const float* pprev, double* out, int B, int C
 int hrseg_group_kl_bwd(const float* z, const float* pprev, const float* g, float scale, float* dz, int B, int C,
                        int Cprev, long hw, int ngroups, const int* group_parent, const int* group_size,
                        hrseg_stream_t stream);
+/* per-class metric vectors of nlevels (1..8) levels from their confusion counts in ONE launch: cm[L] (DEVICE, int64
+ * [K_L][K_L], (target, predicted) as hrseg_predict_metrics counts them), child[L] != 0: label 0 is the synthetic background
+ * of a child level (its row is dropped, its class not reported).  out (DEVICE) receives [5][sum_L (K_L - child_L)] floats:
+ * accuracy (= recall per class, as the reference defines it), iou, dice, precision, recall, levels side by side; a zero
+ * denominator gives 0.  Replaces the ~80 small tensor ops of the reference's metric classes per batch (train.py:47-51,
+ * Metrics/performance_metrics.py).  cm, K, child are HOST arrays. */
+int hrseg_metric_vectors(int nlevels, const long long* const* cm, const int* K, const int* child, float* out,
+                         hrseg_stream_t stream);
 /* argmax one-hot of z masked by t!=-1, plus confusion matrix counts
  * cm[(C+child)*(C+child)] (int64, +=) of (target label, predicted label) with
  * the synthetic background class 0 for child levels. mask_pred=1 is the train

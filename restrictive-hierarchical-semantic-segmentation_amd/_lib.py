@@ -106,6 +106,7 @@ PROTOTYPES = {
     "hrseg_group_kl": [_p, _p, _p, _i, _i, _i, _l, _i, _p, _p, _p],
     "hrseg_group_kl_bwd": [_p, _p, _p, _f, _p, _i, _i, _i, _l, _i, _p, _p, _p],
     "hrseg_predict_metrics": [_p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    "hrseg_metric_vectors": [_i, _p, _p, _p, _p, _p],
     "hrseg_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     "hrseg_adamw_dev": [_p, _p, _p, _p, _l, _p, _p, _p],
     "hrseg_fill": [_p, _f, _l, _p],

@@ -1071,6 +1071,50 @@ extern "C" int hrseg_predict_metrics(const float* z, const float* t, float* oneh
   return 0;
 }
 
+// per-class metric vectors of up to 8 levels from their confusion counts, one launch (Metrics/performance_metrics.py
+// metrics_from_confusion: the reference's IoU / Dice / precision / recall classes, train.py:47-51, evaluated in fp64 on the
+// counts and rounded to fp32; a zero denominator gives 0).  Thread = one (level, class).
+#define METRIC_MAXL 8
+struct MetricLevels { int n, total; const long long* cm[METRIC_MAXL]; int K[METRIC_MAXL], child[METRIC_MAXL], off[METRIC_MAXL]; };
+__global__ void metric_vectors_kernel(MetricLevels a, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int L = 0;
+  while (L + 1 < a.n && i >= a.off[L + 1]) ++L;
+  const int K = a.K[L], ch = a.child[L], c = i - a.off[L] + ch;        // c: label of this class in the K x K matrix
+  const long long* cm = a.cm[L];
+  // child levels: pixels whose TARGET is the synthetic background label 0 are dropped (rows 1..K-1 only)
+  double tp = (double)cm[(long)c * K + c], row = 0.0, col = 0.0;
+  for (int j = 0; j < K; ++j) row += (double)cm[(long)c * K + j];
+  for (int r = ch; r < K; ++r) col += (double)cm[(long)r * K + c];
+  const double fn = row - tp, fp = col - tp;
+  auto sdiv = [](double x, double y) { return y == 0.0 ? 0.f : (float)(x / y); };
+  const float rec = sdiv(tp, tp + fn);
+  out[0 * a.total + i] = rec;                                  // "accuracy" (per-class accuracy = recall, as in the reference)
+  out[1 * a.total + i] = sdiv(tp, tp + fp + fn);               // iou
+  out[2 * a.total + i] = sdiv(2.0 * tp, 2.0 * tp + fp + fn);   // dice
+  out[3 * a.total + i] = sdiv(tp, tp + fp);                    // precision
+  out[4 * a.total + i] = rec;                                  // recall
+}
+extern "C" int hrseg_metric_vectors(int nlevels, const long long* const* cm, const int* K, const int* child, float* out,
+                                    hrseg_stream_t stream) {
+  HRSEG_CHECK_ARG(nlevels >= 1 && nlevels <= METRIC_MAXL && cm && K && child && out, "hrseg_metric_vectors: 1..%d levels", METRIC_MAXL);
+  MetricLevels a;
+  a.n = nlevels;
+  a.total = 0;
+  for (int L = 0; L < nlevels; ++L) {
+    HRSEG_CHECK_ARG(cm[L] && K[L] > (child[L] ? 1 : 0) && K[L] <= MAXC + 1, "hrseg_metric_vectors: level %d: bad matrix", L);
+    a.cm[L] = cm[L];
+    a.K[L] = K[L];
+    a.child[L] = child[L] ? 1 : 0;
+    a.off[L] = a.total;
+    a.total += K[L] - a.child[L];
+  }
+  hipLaunchKernelGGL(metric_vectors_kernel, dim3((a.total + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, out);
+  HRSEG_LAUNCH_CHECK("metric_vectors");
+  return 0;
+}
+
 extern "C" int hrseg_group_kl(const float* z, const float* pprev, double* out, int B, int C, int Cprev, long hw,
                               int ngroups, const int* group_parent, const int* group_size, hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(z && pprev && out && B > 0 && C > 0 && C <= MAXC && Cprev > 0 && Cprev <= MAXC && hw > 0 && ngroups > 0,

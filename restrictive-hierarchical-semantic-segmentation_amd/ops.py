@@ -737,6 +737,18 @@ def predict_metrics(z, t, child, mask_pred=True, want_onehot=True):
     return onehot, cm
 
 
+def metric_vectors(cms, child):
+    """per-level confusion matrices [K,K] int64 (predict_metrics) -> [5][sum C_L] fp32: accuracy, iou, dice, precision,
+    recall of every class, the levels side by side; one launch (hrseg_metric_vectors)"""
+    cms = [_c(cm) for cm in cms]
+    K = [cm.shape[0] for cm in cms]
+    total = sum(k - (1 if ch else 0) for k, ch in zip(K, child))
+    out = torch.empty((5, total), dtype=torch.float32, device=cms[0].device)
+    call("hrseg_metric_vectors", len(cms), _lib.ptr_array(cms), _lib.int_array(K), _lib.int_array([int(bool(c)) for c in child]),
+         ptr(out))
+    return out
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

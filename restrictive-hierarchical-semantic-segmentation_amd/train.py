@@ -149,7 +149,11 @@ def load_checkpoint(path, model, optimizer=None, device="cuda"):
 
 # ----------------------------------------------------------------------------- metrics
 def _metric_vectors(cms):
-    """per-level confusion matrices -> dict name -> [sum C_L] device tensor"""
+    """per-level confusion matrices -> dict name -> [sum C_L] device tensor (one launch: ops.metric_vectors; the per-level
+    tensor form of the same arithmetic is Metrics.performance_metrics.metrics_from_confusion, which the metric classes use)"""
+    if len(cms) <= 8 and cms[0].dtype == torch.int64:
+        vec = ops.metric_vectors(cms, [L > 0 for L in range(len(cms))])
+        return {k: vec[i] for i, k in enumerate(METRIC_NAMES)}
     per = {k: [] for k in METRIC_NAMES}
     for L, cm in enumerate(cms):
         m = metrics_from_confusion(cm, child_classes=(L > 0))

@@ -726,3 +726,27 @@ def test_fuse_sum_one_pass_equals_the_launch_chain(n_same, n_low):
         ref = ref + F.interpolate(a.permute(0, 3, 1, 2).cpu(), size=(H, W), mode="bilinear", align_corners=True)
     ref = torch.relu(ref)
     assert float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_metric_vectors_kernel_equals_the_per_level_tensor_arithmetic(ops):
+    """hrseg_metric_vectors (one launch for all levels) against metrics_from_confusion, the torch-op form the metric classes
+    use and the oracle pins: classes nobody predicted, classes absent from the targets, an all-background child level"""
+    from hrseg_amd.Metrics.performance_metrics import METRIC_NAMES, metrics_from_confusion
+    g = torch.Generator().manual_seed(11)
+    cms = [torch.randint(0, 50000, (4, 4), generator=g), torch.randint(0, 50000, (5, 5), generator=g),
+           torch.randint(0, 9, (8, 8), generator=g), torch.zeros(3, 3, dtype=torch.int64)]
+    cms[0][:, 2] = 0                # class 2 never predicted
+    cms[1][3, :] = 0                # class 3 absent from the targets
+    cms[1][:, 3] = 0                # ... and never predicted: every denominator of that class is zero
+    cms[3][0, 0] = 1234             # a child level that saw background only
+    cms = [c.cuda() for c in cms]
+    child = [False, True, True, True]
+    vec = ops.metric_vectors(cms, child)
+    want = {k: [] for k in METRIC_NAMES}
+    for cm, ch in zip(cms, child):
+        m = metrics_from_confusion(cm, child_classes=ch)
+        for k in METRIC_NAMES:
+            want[k].append(m[k])
+    assert vec.shape == (5, 4 + 4 + 7 + 2)
+    for i, k in enumerate(METRIC_NAMES):
+        assert torch.equal(vec[i], torch.cat(want[k])), k

@@ -101,7 +101,10 @@ def _golden_body(name, model, mode="auto"):
             # BN/ReLU of the net, where fp32 evaluations differ from each other by ~1e-2 already
             # (tests/diagnostics/grad_noise.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
             tol = 5e-2 if key[6:].startswith(("stem", "inc0")) else 5e-3
-            assert np.abs(got - g[key]).max() < tol * np.abs(g[key]).max() + 1e-6, key
+            # absolute floor 2e-6: a head bias gradient is a sum over all pixels that cancels almost completely (the two-class
+            # head of hrnet_hier_ext_62: +-8.9e-6 from terms of ~1e-3), so its value carries the rounding of that sum --
+            # observed 1.15e-6 from the golden in one run of the default routing, 0.3e-6 in others
+            assert np.abs(got - g[key]).max() < tol * np.abs(g[key]).max() + 2e-6, key
     bufs = np.array([float(b.double().norm()) for _, b in model.named_buffers()])
     assert np.max(np.abs(bufs - g["buf_norms"]) / np.maximum(g["buf_norms"], 1e-6)) < TOL
 
