@@ -32,9 +32,9 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
@@ -686,8 +686,10 @@ static void plan_wgrad_blocks(WgradArgs& a, int tn, int tk, int pix, int& gx, in
 }
 
 // returns 1 when the problems cannot share one kernel instance (caller falls back)
-static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
+static int g_wg_group_sp = 1;          // hrseg_tune "wgrad_group_sp": 0 = grouped tap-per-block weight gradients stay on the fp32 kernel
+static int dispatch_wgrad_group(WgradArgs* a, int n, int prec, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wg_pix || g_tune_wg_db || g_tune_wg_blocks) return 1;
+  const bool sp = prec == HRSEG_CONV_FP16X2 && g_wg_group_sp;       // every problem asked for fp16x2 (AUTO resolves to it)
   const int tn = (a[0].Cout % 48 == 0) ? 3 : (a[0].Cout % 64 == 0) ? 4 : 0;
   const int tk = (a[0].Cin % 48 == 0) ? 3 : (a[0].Cin % 64 == 0) ? 4 : 0;
   if (!tn || !tk) return 1;
@@ -697,12 +699,16 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, hipStream_t st) {
   for (int i = 0; i < n; ++i) {
     if (a[i].Cout % (16 * tn) || a[i].Cin % (16 * tk)) return 1;
     int gx, tiles;
-    plan_wgrad_blocks(a[i], tn, tk, 64, gx, tiles);
+    plan_wgrad_blocks(a[i], tn, tk, sp ? 128 : 64, gx, tiles);     // (pixels per stage: SpWgradLds::PIX resp. the fp32 plan)
     if (check_wgrad_span(a[i])) return 1;   // the per-problem launch reports the error
     g.gx[i] = gx;
     end += gx * tiles;
     g.blk_end[i] = end;
     g.a[i] = a[i];
+  }
+  if (sp) {
+    ++g_cnt[CNT_WGRAD_SP_GROUP];
+    return launch_wgrad_group_sp(g, tn, tk, end, st);
   }
   ++g_cnt[CNT_WGRAD_F32_GROUP];
   return launch_wgrad_group_f32(g, tn, tk, end, st);
@@ -960,8 +966,14 @@ extern "C" int hrseg_conv_wgrad_group(int n, const float* const* x, const float*
   }
   if (ok && n >= 2) {
     WgradArgs a[MAXG];
-    for (int i = 0; i < n; ++i) fill_wgrad_args(a[i], x[i], dy[i], dw[i], &shapes[i]);
-    if (dispatch_wgrad_group(a, n, st) == 0) {
+    hrseg_conv_shape_t rs[MAXG];
+    resolve_wgrad_shapes(n, shapes, rs);
+    int prec = rs[0].precision;
+    for (int i = 0; i < n; ++i) {
+      fill_wgrad_args(a[i], x[i], dy[i], dw[i], &rs[i]);
+      if (rs[i].precision != prec) prec = HRSEG_CONV_F32;
+    }
+    if (dispatch_wgrad_group(a, n, prec, st) == 0) {
       HRSEG_LAUNCH_CHECK("wgrad_group");
       return 0;
     }
@@ -1176,7 +1188,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -899,6 +899,20 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(WgradArgs p) {
   wgrad_sp_body<NS, TN, TK>(p, lds, r / tiles, r % tiles);
 }
 
+// several problems in one launch (the fuse layers' 1x1 / stride-2 weight gradients of an HRNet module): blocks
+// [blk_end[g-1], blk_end[g]) belong to problem g, each with its own pixel ranges x (tap, tile) blocks
+template <int NS, int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_sp_group_kernel(WgradGroup grp) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgradLds<NS, TN, TK>::BYTES];
+  int g = 0;
+  while (g + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[g]) ++g;
+  const int lo = g ? grp.blk_end[g - 1] : 0;
+  const int nblk = grp.blk_end[g] - lo;
+  const int tiles = nblk / grp.gx[g];
+  const int r = xcd_remap(blockIdx.x - lo, nblk);
+  wgrad_sp_body<NS, TN, TK>(grp.a[g], lds, r / tiles, r % tiles);
+}
+
 // --------------------------------------------------------------------------- 3x3 stride-1: halo patch in LDS
 // At bf16 matrix rates the im2col body above is bound by the L2 -> CU path: every input pixel is pulled nine
 // times (once per tap) for only 16*WTN output channels (measured: ~8 TB/s of operand traffic whatever the

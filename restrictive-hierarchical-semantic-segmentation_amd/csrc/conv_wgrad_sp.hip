@@ -16,6 +16,12 @@ int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, i
   return ns == 4 ? launch_wgrad_sp<4>(a, tn, tk, gx, tiles, st) : ns == 3 ? launch_wgrad_sp<3>(a, tn, tk, gx, tiles, st)
        : ns == 2 ? launch_wgrad_sp<2>(a, tn, tk, gx, tiles, st) : launch_wgrad_sp<1>(a, tn, tk, gx, tiles, st);
 }
+int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st) {      // fp16x2 only
+#define WGS(TN_, TK_) if (tn == TN_ && tk == TK_) { hipLaunchKernelGGL((wgrad_sp_group_kernel<4, TN_, TK_>), dim3(nblocks), dim3(256), 0, st, g); return 0; }
+  WGS(3, 3) WGS(3, 4) WGS(4, 3) WGS(4, 4)
+#undef WGS
+  return 1;
+}
 int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st, int ws) {
   // role-split form (three consumer + three producer waves).  48-channel tiles: 162 registers, two blocks per CU.  The
   // 64-channel tiling keeps 192 accumulator registers per consumer wave: with six waves per block that spills (a block of

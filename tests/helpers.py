@@ -82,7 +82,7 @@ class conv_mode:
     def __exit__(self, *exc):
         from hrseg_amd import _lib
         for fam in ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group", "wgrad_sp",
-                    "wgrad_f32", "wgrad_f32_group", "wgrad9"):
+                    "wgrad_f32", "wgrad_f32_group", "wgrad9", "wgrad_sp_group"):
             self.counts[fam] = _lib.launch_count(fam, reset=True)
         _lib.tune(sp_ws_min_tiles=0, sp_patch_min_tiles=0, auto_min_pixels=0)      # 0 = defaults
         return False
@@ -94,11 +94,10 @@ class conv_mode:
             assert c["ws"] + c["ws_group"] + c["patch_sp"] + c["sp_im2col"] + c["sp_pgroup"] + c["sp_group"] == 0, c
             assert c["f32"] + c["f32_group"] > 0 and c["wgrad9"] + c["wgrad_sp"] == 0, c
         elif self.mode == "fp16x2":
-            # (grouped weight gradients of 1x1 / stride-2 layers have one kernel family, the exact-fp32 one)
-            assert c["f32"] + c["f32_group"] + c["wgrad_f32"] == 0, c
+            assert c["f32"] + c["f32_group"] + c["wgrad_f32"] + c["wgrad_f32_group"] == 0, c
             assert c["ws"] > 0 and c["wgrad9"] > 0, c
             if kind == "hrnet":
-                assert c["sp_im2col"] > 0 and c["wgrad_sp"] > 0, c
+                assert c["sp_im2col"] > 0 and c["wgrad_sp"] > 0 and c["wgrad_sp_group"] > 0, c
         elif self.mode == "auto_ws":
             assert c["ws"] + c["ws_group"] > 0 and c["wgrad9"] > 0, c
             if kind == "hrnet":

@@ -104,6 +104,44 @@ def test_grouped_branch_convs_in_split_precision(mode):
         assert _rel(dws[i].view(c, 3, 3, c).permute(0, 3, 1, 2), dw) < 4e-5, i
 
 
+@pytest.mark.parametrize("k,s", [(1, 1), (3, 2)])
+@pytest.mark.parametrize("mode", ["fp16x2", "auto"])
+def test_grouped_fuse_layer_weight_gradients_in_split_precision(mode, k, s):
+    """the fuse layers of an HRNet module (1x1 towards the finer branches, 3x3 stride 2 towards the coarser ones): their
+    weight gradients are ONE grouped launch of the tap-per-block split-precision kernel (counter wgrad_sp_group; the fp32
+    grouped kernel with hrseg_tune wgrad_group_sp=0), called twice (the second call accumulates)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION[mode]
+    B = 4
+    if k == 1:
+        cfg = [(96, 48, 40, 48), (192, 48, 20, 24), (384, 48, 10, 12), (192, 96, 20, 24), (384, 192, 10, 12)]
+    else:
+        cfg = [(48, 96, 80, 95), (48, 48, 80, 95), (96, 192, 40, 47), (192, 384, 21, 24)]
+    g = torch.Generator().manual_seed(5 + k)
+    xs, dys, refs = [], [], []
+    for cin, cout, h, w_ in cfg:
+        x = torch.randn(B, cin, h, w_, generator=g)
+        w = torch.zeros(cout, cin, k, k, requires_grad=True)
+        y = F.conv2d(x, w, stride=s, padding=(k - 1) // 2)
+        dy = torch.randn(y.shape, generator=g) * 1e-4
+        y.backward(dy)
+        xs.append(_nhwc(x)), dys.append(_nhwc(dy)), refs.append(w.grad)
+    gm = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    for sp in (1, 0):
+        _lib.tune(wgrad_group_sp=sp)
+        try:
+            dws = [torch.zeros(cout, k * k, cin, device="cuda") for cin, cout, _, _ in cfg]
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad_group(xs, dys, dws, k, s, prec=pr, gmaxs=gm)
+            ops.conv_wgrad_group(xs, dys, dws, k, s, prec=pr, gmaxs=gm)
+            assert _lib.launch_count("wgrad_sp_group") == (2 if sp else 0)
+            assert _lib.launch_count("wgrad_f32_group") == (0 if sp else 2)
+        finally:
+            _lib.tune(wgrad_group_sp=1)
+        for (cin, cout, _, _), dw, ref in zip(cfg, dws, refs):
+            assert _rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), 2 * ref) < 4e-5, (sp, cin, cout)
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: bf16-input convolutions
 # bf16 operands (2^-9 each) through ~300 conv+BN layers at 62x62, where the lowest branch is 2x2 pixels and BatchNorm
 # normalises over 8 samples: measured relative L2 error of the logits 0.10-0.31 (level 0 worst), max-norm error up to 0.47 on single pixels, loss within 0.1 %
