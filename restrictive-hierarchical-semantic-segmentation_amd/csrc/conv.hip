@@ -235,7 +235,7 @@ static const int WS_WTN[5] = {0, 3, 6, 4, 3}, WS_CS[5] = {0, 3, 3, 4, 3}, WS_TH[
 // Canvas mode of the wave-specialised body (conv_sp.h): the images of the batch side by side with a zero column between
 // them, tiled as ONE image.  Taken when it cuts the padded area by at least 5 % (39 x 39: 1.26x -> 1.05x, 20 x 20: 1.92x ->
 // 1.32x at 8 images; the 155 / 78-pixel branches stay per image) and the multiply-high image lookup is exact.
-static int g_ws_canvas = 1;             // hrseg_tune "sp_ws_canvas": 0 = per-image tiles everywhere
+static int g_ws_canvas = 5;             // hrseg_tune "sp_ws_canvas": least cut of the padded area, percent (0 = per-image tiles everywhere)
 static long ws_pixel_tiles(const IgemmArgs& a, int kind, bool canvas) {       // 16-column x TH-row tiles of the whole batch
   const long ty = ceil_div(a.Ho, WS_TH[kind]);
   return canvas ? ty * ceil_div((long)a.B * (a.Wo + 1) - 1, 16) : (long)a.B * ty * ceil_div(a.Wo, 16);
@@ -243,7 +243,7 @@ static long ws_pixel_tiles(const IgemmArgs& a, int kind, bool canvas) {       //
 static bool ws_canvas(const IgemmArgs& a, int kind) {
   if (!g_ws_canvas || a.B < 2 || (long)a.B * (a.Wo + 1) >= 65536) return false;
   if ((long)a.B * a.Ho * a.Wo * a.ldx * 4 >= (1l << 31)) return false;          // one buffer descriptor spans the batch
-  return ws_pixel_tiles(a, kind, true) * 100 <= ws_pixel_tiles(a, kind, false) * 95;
+  return ws_pixel_tiles(a, kind, true) * 100 <= ws_pixel_tiles(a, kind, false) * (100 - g_ws_canvas);
 }
 static long ws_tiles(const IgemmArgs& a, int kind) {
   return ws_pixel_tiles(a, kind, ws_canvas(a, kind)) * (a.N / (16 * WS_WTN[kind]));

@@ -139,14 +139,14 @@ def test_ws_canvas_tiling_bit_identical_to_per_image_tiling(case):
         return (y, yr, dx, acc), _lib.launch_count("ws"), _lib.launch_count("ws_canvas")
 
     try:
-        _lib.tune(sp_ws_canvas=1)
+        _lib.tune(sp_ws_canvas=5)
         on, n_ws, n_cv = run()
         assert n_ws == 4 and n_cv == 4, (n_ws, n_cv)
         _lib.tune(sp_ws_canvas=0)
         off, n_ws, n_cv = run()
         assert n_ws == 4 and n_cv == 0, (n_ws, n_cv)
     finally:
-        _lib.tune(sp_ws_canvas=1, sp_ws_waste=200, sp_ws_min_tiles=0)
+        _lib.tune(sp_ws_canvas=5, sp_ws_waste=200, sp_ws_min_tiles=0)
     for a, b, what in zip(on, off, ("forward", "forward + residual + relu", "data gradient", "accumulating data gradient")):
         assert torch.equal(a, b), f"{what}: canvas and per-image tilings differ"
     assert _rel(on[0].permute(0, 3, 1, 2), y_ref) < TOL
