@@ -32,15 +32,15 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
   for (int i = 0; i < CNT_N; ++i)
-    if (family ? !strcmp(family, g_cnt_names[i]) : i != CNT_WS_CANVAS) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
-  if (!family && reset) g_cnt[CNT_WS_CANVAS] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
+    if (family ? !strcmp(family, g_cnt_names[i]) : (i != CNT_WS_CANVAS && i != CNT_WGRAD_SP_T5)) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+  if (!family && reset) g_cnt[CNT_WS_CANVAS] = g_cnt[CNT_WGRAD_SP_T5] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
   return total;
 }
 
@@ -647,14 +647,31 @@ int check_wgrad_span(const WgradArgs& a) {
   return 0;
 }
 
+static int g_wg_t5 = 1;                // hrseg_tune "wgrad_sp_t5": 0 = no 80 x 80 tiles in the tap-per-block weight gradient
 static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
-  const int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
-  const int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
+  int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+  int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
   constexpr int PIX = 128;                      // SpWgradLds::PIX
+  // Wide layers (720 -> 720 of the HRNet head): 80 x 80 tiles.  The body splits both operands on the fly, (tn + tk) * 12 VALU
+  // per wave and 32 pixels next to tn * tk * 3 MFMAs: at 48 x 48 the split outweighs the MFMAs (MFMA-busy 0.19) and every
+  // operand row is pulled Cin / 48 resp. Cout / 48 = 15 times through L2; at 80 x 80 it is 120 VALU : 75 MFMAs and 9 pulls.
+  // One block per CU (80 KB of LDS): the pixel ranges are sized so that the blocks fill whole rounds of 256.
+  const bool t5 = ns == 4 && g_wg_t5 && a.Cout % 80 == 0 && a.Cin % 80 == 0 && (long)a.Cout * a.Cin >= 240 * 240 && a.M >= 65536;
+  if (t5) tn = tk = 5;
   const int tiles = (a.Cout / (16 * tn)) * (a.Cin / (16 * tk)) * a.T;
   int target = 7 * tiles;
   if (target < 512) target = 512;
   if (target > 4096) target = 4096;
+  if (t5) {
+    int best = 0;
+    double best_eff = 0.0;
+    for (int k = 4; k <= 32 && k * PIX * 8 <= a.M; ++k) {
+      const int blocks = tiles * k;
+      const double eff = (double)blocks / (ceil_div(blocks, 256) * 256.0);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    }
+    if (best) target = best * tiles;
+  }
   if (g_tune_wg_blocks) target = g_tune_wg_blocks;
   int ksplit = target / tiles;
   if (ksplit < 1 || hrseg_g_deterministic) ksplit = 1;
@@ -664,6 +681,7 @@ static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
   if (int e = check_wgrad_span(a)) return e;
   const int gx = ceil_div(a.M, ppb);
   ++g_cnt[CNT_WGRAD_SP];
+  g_cnt[CNT_WGRAD_SP_T5] += t5;      // ("wgrad_sp" launches that used 80 x 80 tiles)
   return launch_wgrad_sp_kernel(ns, a, tn, tk, gx, tiles, st);
 }
 
@@ -1188,7 +1206,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -9,6 +9,7 @@ static int launch_wgrad_sp(const WgradArgs& a, int tn, int tk, int gx, int tiles
 #define WS(TN_, TK_) if (tn == TN_ && tk == TK_) { hipLaunchKernelGGL((wgrad_sp_kernel<NS, TN_, TK_>), dim3(gx, tiles), dim3(256), 0, st, a); return 0; }
   WS(1, 1) WS(1, 2) WS(1, 3) WS(1, 4) WS(2, 1) WS(2, 2) WS(2, 3) WS(2, 4)
   WS(3, 1) WS(3, 2) WS(3, 3) WS(3, 4) WS(4, 1) WS(4, 2) WS(4, 3) WS(4, 4)
+  if constexpr (NS == 4) { WS(5, 5) }       // 80 x 80 tile (80 KB of LDS, one block per CU): the 720-channel layer
 #undef WS
   return HRSEG_ERR_UNSUPPORTED;
 }

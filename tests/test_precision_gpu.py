@@ -142,6 +142,36 @@ def test_grouped_fuse_layer_weight_gradients_in_split_precision(mode, k, s):
             assert _rel(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), 2 * ref) < 4e-5, (sp, cin, cout)
 
 
+def test_wide_layer_weight_gradient_on_80x80_tiles():
+    """the 720 -> 720 head layer's weight gradient (here 240 -> 240 on 73,728 pixels: same routing) runs the tap-per-block
+    kernel on 80 x 80 tiles; same values as on 48 x 48 tiles (hrseg_tune wgrad_sp_t5=0) and as torch, to the fp16x2 tolerance"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(31)
+    B, C, H, W = 2, 240, 192, 192
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.zeros(C, C, 1, 1, requires_grad=True)
+    y = F.conv2d(x, w)
+    dy = torch.randn(y.shape, generator=g) * 1e-3
+    y.backward(dy)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    gmax = dyd.abs().max().reshape(1).repeat(64)
+    got = {}
+    for t5 in (1, 0):
+        _lib.tune(wgrad_sp_t5=t5)
+        try:
+            dw = torch.zeros(C, 1, C, device="cuda")
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad(xd, dyd, dw, 1, 1, prec=pr, gmax=gmax)
+            ops.conv_wgrad(xd, dyd, dw, 1, 1, prec=pr, gmax=gmax)                  # accumulates
+            assert _lib.launch_count("wgrad_sp") == 2 and _lib.launch_count("wgrad_sp_t5") == (2 if t5 else 0)
+        finally:
+            _lib.tune(wgrad_sp_t5=1)
+        got[t5] = dw
+        assert _rel(dw.view(C, 1, 1, C).permute(0, 3, 1, 2), 2 * w.grad) < 4e-5, t5
+    assert _rel(got[1], got[0]) < 2e-5
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: bf16-input convolutions
 # bf16 operands (2^-9 each) through ~300 conv+BN layers at 62x62, where the lowest branch is 2x2 pixels and BatchNorm
 # normalises over 8 samples: measured relative L2 error of the logits 0.10-0.31 (level 0 worst), max-norm error up to 0.47 on single pixels, loss within 0.1 %
