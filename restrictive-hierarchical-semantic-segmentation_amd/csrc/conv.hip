@@ -32,9 +32,9 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_WGRAD_SP_WIDE, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5", "wgrad_sp_wide"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
@@ -648,7 +648,31 @@ int check_wgrad_span(const WgradArgs& a) {
 }
 
 static int g_wg_t5 = 1;                // hrseg_tune "wgrad_sp_t5": 0 = no 80 x 80 tiles in the tap-per-block weight gradient
+static int g_wg_wide = 1;              // hrseg_tune "wgrad_sp_wide": 0 = never the wide-tile weight-gradient body
+// pixel ranges per tile set such that the blocks fill whole rounds of `slots` (one block per CU): the k in [kmin, kmax] with the
+// best fill, the smallest such k on ties
+static int ksplit_for_rounds(int tiles, int kmin, int kmax, int slots) {
+  int best = 0;
+  double best_eff = 0.0;
+  for (int k = kmin; k <= kmax; ++k) {
+    const int blocks = tiles * k;
+    const double eff = (double)blocks / (ceil_div(blocks, slots) * (double)slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+  }
+  return best;
+}
 static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
+  // wide layers whose channels divide into 240 x 144 block tiles (the 720 -> 720 head layer): wgrad_spw_body
+  if (ns == 4 && g_wg_wide && a.Cout % 240 == 0 && a.Cin % 144 == 0 && a.M >= 65536 && !hrseg_g_deterministic && !g_tune_wg_blocks) {
+    const int tiles = (a.Cout / 240) * (a.Cin / 144) * a.T;
+    int kmax = a.M / 2048;                       // at least 64 stages of 32 pixels per block
+    if (kmax > 64) kmax = 64;
+    const int ksplit = ksplit_for_rounds(tiles, 1, kmax, 256);
+    a.pix_per_block = ceil_div(ceil_div(a.M, ksplit), 32) * 32;
+    if (int e = check_wgrad_span(a)) return e;
+    ++g_cnt[CNT_WGRAD_SP_WIDE];
+    return launch_wgrad_spw_kernel(a, ceil_div(a.M, a.pix_per_block), tiles, st);
+  }
   int tn = (a.Cout % 48 == 0) ? 3 : (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
   int tk = (a.Cin % 48 == 0) ? 3 : (a.Cin % 64 == 0) ? 4 : (a.Cin % 32 == 0) ? 2 : 1;
   constexpr int PIX = 128;                      // SpWgradLds::PIX
@@ -663,14 +687,9 @@ static int dispatch_wgrad_sp(int ns, WgradArgs a, hipStream_t st) {
   if (target < 512) target = 512;
   if (target > 4096) target = 4096;
   if (t5) {
-    int best = 0;
-    double best_eff = 0.0;
-    for (int k = 4; k <= 32 && k * PIX * 8 <= a.M; ++k) {
-      const int blocks = tiles * k;
-      const double eff = (double)blocks / (ceil_div(blocks, 256) * 256.0);
-      if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
-    }
-    if (best) target = best * tiles;
+    int kmax = a.M / (PIX * 8);
+    if (kmax > 32) kmax = 32;
+    if (const int best = ksplit_for_rounds(tiles, 4, kmax, 256)) target = best * tiles;
   }
   if (g_tune_wg_blocks) target = g_tune_wg_blocks;
   int ksplit = target / tiles;
@@ -1206,7 +1225,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -899,6 +899,161 @@ __global__ __launch_bounds__(256) void wgrad_sp_kernel(WgradArgs p) {
   wgrad_sp_body<NS, TN, TK>(p, lds, r / tiles, r % tiles);
 }
 
+// --------------------------------------------------------------------------- wide-tile weight gradient
+// The tap-per-block body above gives every wave its own 32 pixels of a stage and the WHOLE tile, so the tile is bounded by
+// one wave's accumulators (80 x 80) and every operand row is pulled Cin / 80 resp. Cout / 80 times: on the 720 -> 720 layer
+// 10 GB through L2 at the ~7.5 TB/s that path delivers = the 1.32 ms the launch takes (MFMA-busy 0.18).  Here the NWR x NWC
+// waves of a block share the 32 pixels of a stage and each owns a (16 TN) x (16 TK) part of the block's (16 TN NWR) x (16 TK NWC)
+// tile (240 x 144 with 3 x 3 waves of 80 x 48): per pixel 384 operand channels are pulled for 34,560 outputs instead of 160
+// for 6,400, no cross-wave reduction, one atomic add per element and block.  Single LDS buffer, the next stage prefetched
+// into registers across the MFMAs; 576 threads, 60 KB of LDS, one block per CU.
+template <int NS, int TN, int TK, int NWR, int NWC>
+struct SpWgradWideLds {
+  static constexpr int PIX = 32;
+  static constexpr int CA = 16 * TN * NWR, CB = 16 * TK * NWC;        // block tile: output channels x input channels
+  static constexpr int SA = sp_row_stride(CA), SB = sp_row_stride(CB);
+  static constexpr int PIECE = PIX * (SA + SB);
+  static constexpr int BYTES = sp_np(NS) * PIECE;
+};
+
+template <int NS, int TN, int TK, int NWR, int NWC>
+__device__ __forceinline__ void wgrad_spw_body(const WgradArgs& p, unsigned char* lds, const int bx, int id) {
+  using L = SpWgradWideLds<NS, TN, TK, NWR, NWC>;
+  constexpr int PIX = L::PIX, SA = L::SA, SB = L::SB, PIECE = L::PIECE, CA = L::CA, CB = L::CB;
+  constexpr int NT = 64 * NWR * NWC;
+  constexpr int QA = CA / 4, QB = CB / 4;                              // float4 columns of a pixel row
+  constexpr int LA = (PIX * QA + NT - 1) / NT, LB = (PIX * QB + NT - 1) / NT;      // loads per thread and stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / NWC, wc = wave % NWC;
+  const int nct = p.Cout / CA, nkt = p.Cin / CB;
+  const int kt = id % nkt;
+  id /= nkt;
+  const int ct = id % nct;
+  const int tap = id / nct;
+  const int n0 = ct * CA, k0 = kt * CB;
+  const int pad = (p.ks - 1) / 2;
+  const int kh = tap / p.ks - pad, kw = tap % p.ks - pad;
+  const int lo = bx * p.pix_per_block;
+  const int hi = min(lo + p.pix_per_block, p.M);
+  const int nstages = (hi - lo + PIX - 1) / PIX;
+  float dyscale, dyinv;
+  sp_pow2_scale(p.dymax, dyscale, dyinv);
+  const int hw = p.Ho * p.Wo;
+  const int b_lo = lo / hw;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)lo * p.lddy, (size_t)max(hi - lo, 0) * p.lddy * 4);
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc(p.x + (size_t)b_lo * p.Hi * p.Wi * p.ldx, (size_t)(p.B - b_lo) * p.Hi * p.Wi * p.ldx * 4);
+
+  f32x4 ra[LA], rb[LB];
+  auto stage_load = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int u = tid + NT * i, r = u / QA, cq = u - r * QA;
+      const int ml = s * PIX + r;
+      const bool ok = (u < PIX * QA) & (lo + ml < hi);
+      ra[i] = buf_load4(rdy, ok ? ((unsigned)ml * (unsigned)p.lddy + (unsigned)(n0 + 4 * cq)) * 4u : HRSEG_BUF_OOB, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int u = tid + NT * i, r = u / QB, cq = u - r * QB;
+      const int m = lo + s * PIX + r;
+      const int b = fdiv(m, hw, p.rcp_hw);
+      const int rem = m - b * hw;
+      const int oy = fdiv(rem, p.Wo, p.rcp_w), ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride + kh, ix = ox * p.stride + kw;
+      const bool ok = (u < PIX * QB) & (m < hi) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      rb[i] = buf_load4(rx, ok ? ((unsigned)(((b - b_lo) * p.Hi + iy) * p.Wi + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * cq)) * 4u
+                               : HRSEG_BUF_OOB, 0);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int u = tid + NT * i, r = u / QA, cq = u - r * QA;
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(ra[i], pc, dyscale);
+      if (u < PIX * QA)
+#pragma unroll
+        for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(lds + q * PIECE + r * SA + cq * 8) = pc[q];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int u = tid + NT * i, r = u / QB, cq = u - r * QB;
+      u32x2 pc[sp_np(NS)];
+      sp_split4<NS>(rb[i], pc);
+      if (u < PIX * QB)
+#pragma unroll
+        for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(lds + q * PIECE + PIX * SA + r * SB + cq * 8) = pc[q];
+    }
+  };
+
+  f32x4 acc[TN][TK];
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k) acc[n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addresses (as in wgrad_sp_body; all waves read the SAME 32 pixels, their own channel columns)
+  const int g = lane >> 4, li = lane & 15;
+  const int prow = 4 * g + (li >> 2);
+  const int aoff = prow * SA + (li & 3) * 8 + wr * TN * 32, boff = PIX * SA + prow * SB + (li & 3) * 8 + wc * TK * 32;
+
+  if (nstages > 0) {
+    stage_load(0);
+    stage_store();
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) stage_load(s + 1);
+    bf16x8 afr[TN][sp_np(NS)];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
+        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + aoff + n * 32);
+        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + aoff + n * 32 + 16 * SA);
+        afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      bf16x8 bfr[sp_np(NS)];
+#pragma unroll
+      for (int pc = 0; pc < sp_np(NS); ++pc) {
+        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + boff + k * 32);
+        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + boff + k * 32 + 16 * SB);
+        bfr[pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+      }
+#pragma unroll
+      for (int pr = 0; pr < sp_nprod(NS); ++pr)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[n][k] = sp_mma_p<NS>(pr, afr[n], bfr, acc[n][k]);
+    }
+    __syncthreads();                       // every wave is done reading before the image is rewritten
+    if (more) stage_store();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = n0 + (wr * TN + n) * 16 + 4 * g + e;       // D row = 4*(lane>>4)+reg
+        const int ci = k0 + (wc * TK + k) * 16 + li;              // D col = lane&15
+        atomicAdd(p.dw + ((size_t)co * p.T + tap) * p.Cin + ci, NS == 4 ? acc[n][k][e] * dyinv : acc[n][k][e]);
+      }
+}
+
+template <int NS, int TN, int TK, int NWR, int NWC>
+__global__ __launch_bounds__(64 * NWR * NWC) void wgrad_spw_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgradWideLds<NS, TN, TK, NWR, NWC>::BYTES];
+  const int tiles = gridDim.y, nblk = gridDim.x * gridDim.y;
+  const int r = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk);
+  wgrad_spw_body<NS, TN, TK, NWR, NWC>(p, lds, r / tiles, r % tiles);
+}
+
 // several problems in one launch (the fuse layers' 1x1 / stride-2 weight gradients of an HRNet module): blocks
 // [blk_end[g-1], blk_end[g]) belong to problem g, each with its own pixel ranges x (tap, tile) blocks
 template <int NS, int TN, int TK>

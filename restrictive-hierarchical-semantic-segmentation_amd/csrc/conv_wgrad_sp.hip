@@ -17,6 +17,10 @@ int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, i
   return ns == 4 ? launch_wgrad_sp<4>(a, tn, tk, gx, tiles, st) : ns == 3 ? launch_wgrad_sp<3>(a, tn, tk, gx, tiles, st)
        : ns == 2 ? launch_wgrad_sp<2>(a, tn, tk, gx, tiles, st) : launch_wgrad_sp<1>(a, tn, tk, gx, tiles, st);
 }
+int launch_wgrad_spw_kernel(const WgradArgs& a, int gx, int tiles, hipStream_t st) {       // fp16x2, 240 x 144 block tiles
+  hipLaunchKernelGGL((wgrad_spw_kernel<4, 5, 3, 3, 3>), dim3(gx, tiles), dim3(576), 0, st, a);
+  return 0;
+}
 int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st) {      // fp16x2 only
 #define WGS(TN_, TK_) if (tn == TN_ && tk == TK_) { hipLaunchKernelGGL((wgrad_sp_group_kernel<4, TN_, TK_>), dim3(nblocks), dim3(256), 0, st, g); return 0; }
   WGS(3, 3) WGS(3, 4) WGS(4, 3) WGS(4, 4)

@@ -172,6 +172,39 @@ def test_wide_layer_weight_gradient_on_80x80_tiles():
     assert _rel(got[1], got[0]) < 2e-5
 
 
+@pytest.mark.parametrize("k,s_", [(1, 1), (3, 2)])       # (3x3 stride 1 belongs to the nine-tap kernels)
+def test_wide_tile_weight_gradient_body(k, s_):
+    """wgrad_spw_body (240 x 144 block tiles, nine waves sharing the pixels of a stage; the 720 -> 720 head layer's routing):
+    144 -> 240 channels on 73,728 output pixels, 1x1 and the 3x3 stride-2 tap geometry (image borders), ragged last
+    pixel range; against torch and against the tap-per-block body (hrseg_tune wgrad_sp_wide=0), called twice (accumulates)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(41 + k + s_)
+    B, Cin, Cout = 2, 144, 240
+    H, W = (192, 193) if s_ == 1 else (383, 386)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    y = F.conv2d(x, w, stride=s_, padding=(k - 1) // 2)
+    dy = torch.randn(y.shape, generator=g) * 1e-3
+    y.backward(dy)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    gmax = dyd.abs().max().reshape(1).repeat(64)
+    got = {}
+    for wide in (1, 0):
+        _lib.tune(wgrad_sp_wide=wide)
+        try:
+            dw = torch.zeros(Cout, k * k, Cin, device="cuda")
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad(xd, dyd, dw, k, s_, prec=pr, gmax=gmax)
+            ops.conv_wgrad(xd, dyd, dw, k, s_, prec=pr, gmax=gmax)
+            assert _lib.launch_count("wgrad_sp_wide") == (2 if wide else 0) and _lib.launch_count("wgrad_sp") == (0 if wide else 2)
+        finally:
+            _lib.tune(wgrad_sp_wide=1)
+        got[wide] = dw
+        assert _rel(dw.view(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * w.grad) < 4e-5, wide
+    assert _rel(got[1], got[0]) < 2e-5
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: bf16-input convolutions
 # bf16 operands (2^-9 each) through ~300 conv+BN layers at 62x62, where the lowest branch is 2x2 pixels and BatchNorm
 # normalises over 8 samples: measured relative L2 error of the logits 0.10-0.31 (level 0 worst), max-norm error up to 0.47 on single pixels, loss within 0.1 %
