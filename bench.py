@@ -606,6 +606,12 @@ def main():
             # the level passes run batched: every conv launch sees batch * L images
             n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1
             line["roofline"] = probe_dominant_kernel(device, args.batch * n_pass, args.size, conv_dtype)
+            if args.model != "hrnet":
+                # the probe times the parallel-branch launch mix of HRNet (the headline's dominant kernel) at this line's
+                # batch; the recorded counters belong to the HRNet step and are not quoted on another model's line
+                line["roofline"].update(mfma_busy=None, traffic=None, mfma_busy_source="HRNet-step counters: not quoted on this line",
+                                        traffic_source="HRNet-step counters: not quoted on this line",
+                                        note="kernel probe = HRNet branch mix (the wave-specialised 3x3 kernel this model's convolutions also run), not this model's own launch mix")
             if args.model == "hrnet":
                 line["roofline_other"] = probe_secondary_kernels(device, args.batch * n_pass, args.size, conv_dtype)
             log("probe: %s" % json.dumps(line["roofline"]))
