@@ -130,7 +130,7 @@ int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* 
 /* launches issued so far by kernel family ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32",
  * "f32_group", "wgrad_sp", "wgrad_sp_group", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide"; NULL = all); reset != 0
  * zeroes what it returns.  "ws_canvas" counts PROBLEMS (not launches, not part of the NULL total) that a "ws" / "ws_group"
- * launch tiled as one canvas of side-by-side images, "wgrad_sp_t5" the "wgrad_sp" launches on 80 x 80 tiles ("wgrad_sp_wide": the wide-tile weight-gradient kernel, a family of its own).  The parity tests use it to prove which kernels a case ran. */
+ * launch tiled as one canvas of side-by-side images, "wgrad_sp_t5" the "wgrad_sp" launches on 80 x 80 tiles ("wgrad_sp_wide": the wide-tile weight-gradient kernel, a family of its own), "wgrad9_wide" the "wgrad9" calls in which some problems ran the wide nine-tap form.  The parity tests use it to prove which kernels a case ran. */
 long hrseg_launch_count(const char* family, int reset);
 /* tile-plan overrides and A/B switches for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
@@ -138,7 +138,7 @@ long hrseg_launch_count(const char* family, int reset);
  * kernels); sp_ws (0: never use the wave-specialised 3x3 kernels), sp_ws_n48 (0: 48-channel tilings stay on the
  * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_canvas (0: tile every image on its own, never the batch as one
  * canvas), sp_img (0: block-synchronous kernels
- * split their weights on the fly); wgrad9, wgrad9_blocks (nine-tap weight gradient); wgrad_group_sp (0: grouped tap-per-block
+ * split their weights on the fly); wgrad9, wgrad9_blocks, wgrad9_wide (nine-tap weight gradient; 1: the wide form, measured slower, default 0); wgrad_group_sp (0: grouped tap-per-block
  * weight gradients stay on the fp32 kernel), wgrad_sp_t5 (0: no 80 x 80 tiles for the wide layers), wgrad_sp_wide (0: never the wide-tile weight-gradient body); deterministic (1: single-adder
  * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
  * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */

@@ -32,15 +32,15 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_WGRAD_SP_WIDE, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_WGRAD_SP_WIDE, CNT_WGRAD9_WIDE, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5", "wgrad_sp_wide"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5", "wgrad_sp_wide", "wgrad9_wide"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
   for (int i = 0; i < CNT_N; ++i)
-    if (family ? !strcmp(family, g_cnt_names[i]) : (i != CNT_WS_CANVAS && i != CNT_WGRAD_SP_T5)) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
-  if (!family && reset) g_cnt[CNT_WS_CANVAS] = g_cnt[CNT_WGRAD_SP_T5] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
+    if (family ? !strcmp(family, g_cnt_names[i]) : (i != CNT_WS_CANVAS && i != CNT_WGRAD_SP_T5 && i != CNT_WGRAD9_WIDE)) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+  if (!family && reset) g_cnt[CNT_WS_CANVAS] = g_cnt[CNT_WGRAD_SP_T5] = g_cnt[CNT_WGRAD9_WIDE] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
   return total;
 }
 
@@ -764,58 +764,119 @@ static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   return 0;
 }
 // `group_n` problems share the launch: two blocks fit a CU, so the launch's blocks should fill whole rounds of 512 --
-// 256 per problem for one, two or four problems, 1024 / 3 for three (measured on the three-branch group: 139 -> 127 us)
-static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n) {
+// 256 per problem for one, two or four problems, 1024 / 3 for three (measured on the three-branch group: 139 -> 127 us);
+// `lone`: the one narrow problem of a call whose other problems take the wide form (its launch has the chip to itself: 512)
+static void wgrad9_geometry(const hrseg_conv_shape_t& s, Wgrad9Args& a) {
   a.B = s.B; a.H = s.Hi; a.W = s.Wi; a.Cin = s.Cin; a.Cout = s.Cout; a.ldx = s.ldx; a.lddy = s.ldy;
   a.tiles_x = ceil_div(s.Wi, 16); a.tiles_y = ceil_div(s.Hi, 4);
   a.ntiles = s.B * a.tiles_x * a.tiles_y;
-  const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
-  const int target = g_wg9_blocks ? g_wg9_blocks : (group_n == 3 ? 341 : 256);
-  int chunks = (group_n == 3 && !g_wg9_blocks) ? target / npairs : ceil_div(target, npairs);
+}
+static void wgrad9_set_chunks(Wgrad9Args& a, int chunks) {
   if (chunks > a.ntiles) chunks = a.ntiles;
   if (chunks < 1) chunks = 1;
   a.per = ceil_div(a.ntiles, chunks);
   a.nchunks = ceil_div(a.ntiles, a.per);
 }
+static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n, bool lone = false) {
+  wgrad9_geometry(s, a);
+  const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
+  const int target = g_wg9_blocks ? g_wg9_blocks : lone ? 512 : (group_n == 3 ? 341 : 256);
+  wgrad9_set_chunks(a, (group_n == 3 && !g_wg9_blocks) ? target / npairs : ceil_div(target, npairs));
+}
+// The wide form (wgrad9_wide_body): kind 1 = 96 x 48 block tiles (output x input channels) for the 48-channel tiling.  (The
+// 64-channel tiling keeps 192 accumulator registers per wave and only fits with one three-wave block per CU: no wide form.)
+// MEASURED SLOWER and therefore off by default (same box, tools/conv_census.py): three-branch group 120.1 -> 129.2 us, four-branch
+// 158.6 -> 165.6 us, two-branch 71.3 -> 91.0 us, the step 52.0 -> 52.35 ms.  The staging per MFMA does drop by 31 %, but one
+// six-wave block per CU passes every barrier in lock-step, where two independent three-wave blocks drift apart and overlap one
+// block's staging with the other's MFMAs; and the 48-channel branch needs a launch of its own.
+static int g_wg9_wide = 0;             // hrseg_tune "wgrad9_wide": 1 = 96-channel and wider problems on the wide form
+static const int WG9W_CA[2] = {0, 96}, WG9W_CB[2] = {0, 48};
+static int wgrad9_wide_kind(const hrseg_conv_shape_t& s, int tnk) {
+  if (!g_wg9_wide || sp_pieces(s.precision) != 4 || tnk != 3) return 0;
+  return (s.Cout % WG9W_CA[1] == 0 && s.Cin % WG9W_CB[1] == 0) ? 1 : 0;
+}
+// plan of one call: which problems take the wide form, and every problem's pixel chunks.  The wide launch has ONE round of
+// 256 six-wave blocks (one per CU), shared among its problems in proportion to their tile-pair counts.
+struct Wg9Plan { int tnk, n_narrow, n_wide, kind[WG9_MAXG]; Wgrad9Args a[WG9_MAXG]; };
+static bool wgrad9_plan_all(int n, const hrseg_conv_shape_t* shapes, Wg9Plan& pl) {
+  if (n < 1 || n > WG9_MAXG) return false;
+  pl.tnk = wgrad9_tnk(shapes[0]);
+  if (!pl.tnk) return false;
+  pl.n_narrow = pl.n_wide = 0;
+  long work[WG9_MAXG], total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (wgrad9_tnk(shapes[i]) != pl.tnk || shapes[i].precision != shapes[0].precision) return false;
+    pl.kind[i] = wgrad9_wide_kind(shapes[i], pl.tnk);
+    if (pl.kind[i]) {
+      wgrad9_geometry(shapes[i], pl.a[i]);
+      work[i] = (long)pl.a[i].ntiles * (shapes[i].Cout / WG9W_CA[pl.kind[i]]) * (shapes[i].Cin / WG9W_CB[pl.kind[i]]);
+      total += work[i];
+      ++pl.n_wide;
+    } else {
+      ++pl.n_narrow;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (!pl.kind[i]) {
+      wgrad9_plan(shapes[i], pl.tnk, pl.a[i], pl.n_narrow, pl.n_narrow == 1 && pl.n_wide > 0 && pl.tnk == 3);
+      continue;
+    }
+    const int npairs = (shapes[i].Cout / WG9W_CA[pl.kind[i]]) * (shapes[i].Cin / WG9W_CB[pl.kind[i]]);
+    const long blocks = g_wg9_blocks ? g_wg9_blocks : (256 * work[i] + total / 2) / total;
+    wgrad9_set_chunks(pl.a[i], (int)((blocks + npairs / 2) / npairs));
+  }
+  return true;
+}
 // bytes of workspace the nine-tap path wants for these problems (0: not applicable to all of them)
 static size_t wgrad9_ws_bytes(int n, const hrseg_conv_shape_t* shapes) {
-  if (n < 1 || n > WG9_MAXG) return 0;
-  const int tnk = wgrad9_tnk(shapes[0]);
-  if (!tnk) return 0;
+  Wg9Plan pl;
+  if (!wgrad9_plan_all(n, shapes, pl)) return 0;
   size_t total = 0;
-  for (int i = 0; i < n; ++i) {
-    if (wgrad9_tnk(shapes[i]) != tnk || shapes[i].precision != shapes[0].precision) return 0;
-    Wgrad9Args a;
-    wgrad9_plan(shapes[i], tnk, a, n);
-    total += (size_t)a.nchunks * shapes[i].Cout * 9 * shapes[i].Cin * 4;
-  }
+  for (int i = 0; i < n; ++i) total += (size_t)pl.a[i].nchunks * shapes[i].Cout * 9 * shapes[i].Cin * 4;
   return total;
 }
 static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy, float* const* dw,
                            const hrseg_conv_shape_t* shapes, float* ws, hipStream_t st) {
-  const int tnk = wgrad9_tnk(shapes[0]), ns = sp_pieces(shapes[0].precision);
-  Wgrad9Group g;
+  const int ns = sp_pieces(shapes[0].precision);
+  Wg9Plan pl;
+  if (!wgrad9_plan_all(n, shapes, pl)) return HRSEG_ERR_UNSUPPORTED;      // (the caller asked wgrad9_ws_bytes first)
+  const int tnk = pl.tnk;
+  Wgrad9Group gn, gw;                  // narrow and wide launches of this call; one reduce for all problems
   Wgrad9Reduce r;
-  g.n = r.n = n;
-  g.xcd = g_wg9_xcd;
-  int end = 0, rend = 0;
+  gn.n = gw.n = 0;
+  r.n = n;
+  gn.xcd = gw.xcd = g_wg9_xcd;
+  int endn = 0, endw = 0, rend = 0, wkind = 0;
   for (int i = 0; i < n; ++i) {
-    Wgrad9Args& a = g.a[i];
-    wgrad9_plan(shapes[i], tnk, a, n);
+    Wgrad9Args& a = pl.a[i];
     a.x = x[i]; a.dy = dy[i]; a.ws = ws;
     a.dymax = shapes[i].precision == HRSEG_CONV_FP16X2 ? shapes[i].grad_absmax : nullptr;
     HRSEG_CHECK_ARG((double)shapes[i].Hi * shapes[i].Wi * (double)(shapes[i].ldx > shapes[i].ldy ? shapes[i].ldx : shapes[i].ldy) * 4.0 < 4294967296.0,
                     "wgrad9: one image exceeds the 4 GB buffer-offset range");
     const long elems = (long)shapes[i].Cout * 9 * shapes[i].Cin;
-    end += (shapes[i].Cout / (16 * tnk)) * (shapes[i].Cin / (16 * tnk)) * a.nchunks;
-    g.blk_end[i] = end;
+    if (pl.kind[i]) {
+      wkind = pl.kind[i];
+      endw += (shapes[i].Cout / WG9W_CA[wkind]) * (shapes[i].Cin / WG9W_CB[wkind]) * a.nchunks;
+      gw.blk_end[gw.n] = endw;
+      gw.a[gw.n++] = a;
+    } else {
+      endn += (shapes[i].Cout / (16 * tnk)) * (shapes[i].Cin / (16 * tnk)) * a.nchunks;
+      gn.blk_end[gn.n] = endn;
+      gn.a[gn.n++] = a;
+    }
     r.ws[i] = ws; r.dw[i] = dw[i]; r.nchunks[i] = a.nchunks; r.n4[i] = elems / 4;
     rend += (int)((elems / 4 + 31) / 32 < 2048 ? (elems / 4 + 31) / 32 : 2048);
     r.blk_end[i] = rend;
     ws += (size_t)a.nchunks * elems;
   }
   ++g_cnt[CNT_WGRAD9];
-  return launch_wgrad9_kernels(ns, tnk, g, end, r, rend, st, g_wg9_ws);
+  if (gn.n)
+    if (int e = launch_wgrad9_kernels(ns, tnk, gn, endn, r, 0, st, g_wg9_ws)) return e;
+  if (gw.n) {
+    ++g_cnt[CNT_WGRAD9_WIDE];
+    if (int e = launch_wgrad9_wide(wkind, gw, endw, st)) return e;
+  }
+  return launch_wgrad9_reduce(r, rend, st);
 }
 
 // --------------------------------------------------------------------------- weight transpose
@@ -1225,7 +1286,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -27,6 +27,18 @@ int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipS
 #undef WGS
   return 1;
 }
+// the wide form (fp16x2): two output-channel tiles of 48 per block share one x patch (96 x 48 block tile, six waves)
+int launch_wgrad9_wide(int kind, const Wgrad9Group& g, int nblocks, hipStream_t st) {
+  if (kind != 1) return HRSEG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 3, 2, 1>), dim3(nblocks), dim3(384), 0, st, g);
+  HRSEG_LAUNCH_CHECK("wgrad9_wide");
+  return 0;
+}
+int launch_wgrad9_reduce(const Wgrad9Reduce& r, int rblocks, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
+  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+  return 0;
+}
 int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st, int ws) {
   // role-split form (three consumer + three producer waves).  48-channel tiles: 162 registers, two blocks per CU.  The
   // 64-channel tiling keeps 192 accumulator registers per consumer wave: with six waves per block that spills (a block of
@@ -35,8 +47,10 @@ int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, co
     if (tnk == 3) hipLaunchKernelGGL((wgrad9_ws_group_kernel3<4>), dim3(nblocks), dim3(384), 0, st, g);
     else hipLaunchKernelGGL((wgrad9_ws_group_kernel4<4>), dim3(nblocks), dim3(384), 0, st, g);
     HRSEG_LAUNCH_CHECK("wgrad9_ws");
-    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
-    HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+    if (rblocks > 0) {
+      hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
+      HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+    }
     return 0;
   }
 #define W9(NS_) if (ns == NS_) { \
@@ -45,7 +59,9 @@ int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, co
   W9(1) W9(2) W9(3) W9(4)
 #undef W9
   HRSEG_LAUNCH_CHECK("wgrad9");
-  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
-  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+  if (rblocks > 0) {                      // (0: the caller reduces later, after the wide-form launch of the same call)
+    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
+    HRSEG_LAUNCH_CHECK("wgrad9_reduce");
+  }
   return 0;
 }

@@ -322,7 +322,7 @@ def test_role_split_wgrad9_bit_identical_to_block_synchronous(n):
             assert _lib.launch_count("wgrad9") == 1
             outs.append(dws)
     finally:
-        _lib.tune(wgrad9_ws=1)
+        _lib.tune(wgrad9_ws=0)
     for a, b, x, dy, b0, c in zip(outs[0], outs[1], xs, dys, base, chans):
         assert torch.equal(a, b), "role-split and block-synchronous weight gradients differ"
         xr = x.permute(0, 3, 1, 2).cpu().requires_grad_(False)
@@ -330,3 +330,36 @@ def test_role_split_wgrad9_bit_identical_to_block_synchronous(n):
         F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
         got = (a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu()
         assert _rel(got, wr.grad) < 4e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_wide_wgrad9_matches_the_one_pair_per_block_kernels(n):
+    """the wide nine-tap weight gradient (opt-in, hrseg_tune wgrad9_wide=1: two 48-channel output tiles of a block share one
+    staged x patch; the 96-channel and wider branches) against the one-pair-per-block kernels and torch; ragged image edges, accumulation into an existing
+    gradient, the 48-channel branch staying on the narrow kernel in the same call; bit-reproducible (ordered reduce)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(50 + n)
+    chans, sizes = [96, 48, 192, 384][:n], [(31, 42), (61, 83), (16, 21), (8, 11)][:n]
+    xs = [torch.randn(5, h, w, c, generator=g).cuda() for c, (h, w) in zip(chans, sizes)]
+    dys = [(torch.randn(5, h, w, c, generator=g) * 1e-3).cuda() for c, (h, w) in zip(chans, sizes)]
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    base = [torch.randn(c, 9, c, generator=g).cuda() for c in chans]
+    outs = {}
+    try:
+        for wide in (1, 0, 11):
+            _lib.tune(wgrad9_wide=wide % 10)
+            dws = [b.clone() for b in base]
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
+            assert _lib.launch_count("wgrad9") == 1 and _lib.launch_count("wgrad9_wide") == (1 if wide else 0)
+            outs[wide] = dws
+    finally:
+        _lib.tune(wgrad9_wide=0)             # (the default: the wide form measured slower on the branch groups)
+    for a, a2, b, x, dy, b0, c in zip(outs[1], outs[11], outs[0], xs, dys, base, chans):
+        assert torch.equal(a, a2), "two runs of the wide form differ"
+        assert _rel(a - b0, b - b0) < 2e-5
+        xr = x.permute(0, 3, 1, 2).cpu()
+        wr = torch.zeros(c, c, 3, 3, requires_grad=True)
+        F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
+        assert _rel((a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
