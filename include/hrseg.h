@@ -138,7 +138,8 @@ long hrseg_launch_count(const char* family, int reset);
  * kernels); sp_ws (0: never use the wave-specialised 3x3 kernels), sp_ws_n48 (0: 48-channel tilings stay on the
  * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_canvas (0: tile every image on its own, never the batch as one
  * canvas), sp_img (0: block-synchronous kernels
- * split their weights on the fly); wgrad9, wgrad9_blocks, wgrad9_wide (nine-tap weight gradient; 1: the wide form, measured slower, default 0); wgrad_group_sp (0: grouped tap-per-block
+ * split their weights on the fly); wgrad9, wgrad9_blocks, wgrad9_wide, wgrad9_split4 (nine-tap weight gradient; 1: the wide form resp. the six-wave form of the
+ * 64-channel tiling, both measured slower, default 0); wgrad_group_sp (0: grouped tap-per-block
  * weight gradients stay on the fp32 kernel), wgrad_sp_t5 (0: no 80 x 80 tiles for the wide layers), wgrad_sp_wide (0: never the wide-tile weight-gradient body); deterministic (1: single-adder
  * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
  * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */

@@ -790,9 +790,16 @@ static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int
 // six-wave block per CU passes every barrier in lock-step, where two independent three-wave blocks drift apart and overlap one
 // block's staging with the other's MFMAs; and the 48-channel branch needs a launch of its own.
 static int g_wg9_wide = 0;             // hrseg_tune "wgrad9_wide": 1 = 96-channel and wider problems on the wide form
-static const int WG9W_CA[2] = {0, 96}, WG9W_CB[2] = {0, 48};
+// kind 2 (hrseg_tune "wgrad9_split4"): the 64-channel tiling with SIX waves per block -- same 64 x 64 block tile, pixel chunks
+// and workspace as wgrad9_sp_group_kernel4, but every kernel row's 4 x 4 tiles are shared by two waves (4 x 2 each; 204
+// registers, bit-identical results).  Three waves per CU leave one SIMD idle, so this looked like free MFMA capacity; MEASURED:
+// UNet step 42.53 -> 43.91 ms, HRNet 52.15 -> 52.32 (three / two runs each, same box).  Off by default.
+static int g_wg9_split4 = 0;
+static const int WG9W_CA[3] = {0, 96, 64}, WG9W_CB[3] = {0, 48, 64};
 static int wgrad9_wide_kind(const hrseg_conv_shape_t& s, int tnk) {
-  if (!g_wg9_wide || sp_pieces(s.precision) != 4 || tnk != 3) return 0;
+  if (sp_pieces(s.precision) != 4) return 0;
+  if (tnk == 4) return g_wg9_split4 ? 2 : 0;
+  if (!g_wg9_wide) return 0;
   return (s.Cout % WG9W_CA[1] == 0 && s.Cin % WG9W_CB[1] == 0) ? 1 : 0;
 }
 // plan of one call: which problems take the wide form, and every problem's pixel chunks.  The wide launch has ONE round of
@@ -817,6 +824,10 @@ static bool wgrad9_plan_all(int n, const hrseg_conv_shape_t* shapes, Wg9Plan& pl
     }
   }
   for (int i = 0; i < n; ++i) {
+    if (pl.kind[i] == 2) {               // the narrow kernel's work list, run by six-wave blocks
+      wgrad9_plan(shapes[i], pl.tnk, pl.a[i], n);
+      continue;
+    }
     if (!pl.kind[i]) {
       wgrad9_plan(shapes[i], pl.tnk, pl.a[i], pl.n_narrow, pl.n_narrow == 1 && pl.n_wide > 0 && pl.tnk == 3);
       continue;
@@ -1286,7 +1297,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -2216,29 +2216,29 @@ __global__ __launch_bounds__(192) void wgrad9_sp_group_kernel4(Wgrad9Group grp) 
 // MFMA, 8 loads per thread and tile instead of 11.  (2 x 2 waves would halve the staging but twelve waves per CU allow 168
 // registers where the body needs ~240: 93 spilled; the 64-channel tiling has 192 accumulator registers per wave and no wide form.)
 // Tile walk, MFMA order inside a tile and the workspace layout are those of wgrad9_sp_body (same ordered reduce afterwards).
-template <int NS, int TNK, int WN, int WK>
+template <int NS, int TN, int TK, int WN, int WK>
 struct SpWgrad9WideLds {
-  static constexpr int SA = sp_row_stride(16 * TNK * WN), SB = sp_row_stride(16 * TNK * WK);   // bytes per pixel row: dy tile, x patch
+  static constexpr int SA = sp_row_stride(16 * TN * WN), SB = sp_row_stride(16 * TK * WK);   // bytes per pixel row: dy tile, x patch
   static constexpr int DYPIX = 64, XPIX = 6 * 18;
   static constexpr int PIECE = DYPIX * SA + XPIX * SB;
   static constexpr int BYTES = sp_np(NS) * PIECE;
 };
 
-template <int NS, int TNK, int WN, int WK>
+template <int NS, int TN, int TK, int WN, int WK>
 __device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned char* lds, const int pair, const int chunk) {
-  using L = SpWgrad9WideLds<NS, TNK, WN, WK>;
+  using L = SpWgrad9WideLds<NS, TN, TK, WN, WK>;
   constexpr int SA = L::SA, SB = L::SB, PIECE = L::PIECE, XBASE = L::DYPIX * SA;
   constexpr int NT = 192 * WN * WK;
-  constexpr int GA = 4 * TNK * WN, GB = 4 * TNK * WK;          // 16-byte granules per pixel: dy tile, x patch
+  constexpr int GA = 4 * TN * WN, GB = 4 * TK * WK;          // 16-byte granules per pixel: dy tile, x patch
   static_assert(NT % GA == 0 && NT % GB == 0, "a staging round covers whole pixels");
   constexpr int PRA = NT / GA, PRB = NT / GB;                  // pixels per round
   constexpr int DY_LOADS = (L::DYPIX + PRA - 1) / PRA, X_LOADS = (L::XPIX + PRB - 1) / PRB, LOADS = DY_LOADS + X_LOADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kh = wave % 3, sub = wave / 3, wn = sub / WK, wk = sub - wn * WK;      // kernel row, sub-tile of the block tile
   const int g = lane >> 4, li = lane & 15;
-  const int nkt = p.Cin / (16 * TNK * WK);
+  const int nkt = p.Cin / (16 * TK * WK);
   const int ct = pair / nkt, kt = pair - ct * nkt;
-  const int n0 = ct * 16 * TNK * WN, k0 = kt * 16 * TNK * WK;
+  const int n0 = ct * 16 * TN * WN, k0 = kt * 16 * TK * WK;
   const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
   float dyscale, dyinv;
   sp_pow2_scale(p.dymax, dyscale, dyinv);
@@ -2285,17 +2285,17 @@ __device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned c
     }
   };
 
-  f32x4 acc[3][TNK][TNK];
+  f32x4 acc[3][TN][TK];
 #pragma unroll
   for (int w = 0; w < 3; ++w)
 #pragma unroll
-    for (int n = 0; n < TNK; ++n)
+    for (int n = 0; n < TN; ++n)
 #pragma unroll
-      for (int k = 0; k < TNK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < TK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lrow = li >> 2, lcol = (li & 3) * 8;
-  const int dy_lane = (4 * g + lrow) * SA + lcol + wn * TNK * 32;                       // + (2ks+h)*16*SA + n*32
-  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * SB + lcol + wk * TNK * 32;      // + ((2ks+h)*18 + kw)*SB + k*32
+  const int dy_lane = (4 * g + lrow) * SA + lcol + wn * TN * 32;                       // + (2ks+h)*16*SA + n*32
+  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * SB + lcol + wk * TK * 32;      // + ((2ks+h)*18 + kw)*SB + k*32
 
   if (t_lo < t_hi) tile_load(t_lo);
   for (int t = t_lo; t < t_hi; ++t) {
@@ -2303,10 +2303,10 @@ __device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned c
     tile_store();
     if (t + 1 < t_hi) tile_load(t + 1);      // in flight behind this tile's MFMAs
     __syncthreads();
-    bf16x8 afr[TNK][sp_np(NS)], bfr[TNK][sp_np(NS)];
+    bf16x8 afr[TN][sp_np(NS)], bfr[TK][sp_np(NS)];
     auto read_a = [&](int ks) {
 #pragma unroll
-      for (int n = 0; n < TNK; ++n)
+      for (int n = 0; n < TN; ++n)
 #pragma unroll
         for (int pc = 0; pc < sp_np(NS); ++pc) {
           const s16x4 v0 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks) * 16 * SA + n * 32);
@@ -2325,17 +2325,17 @@ __device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned c
     };
     read_a(0);
 #pragma unroll
-    for (int k = 0; k < TNK; ++k) read_b(0, k);
+    for (int k = 0; k < TK; ++k) read_b(0, k);
 #pragma unroll
     for (int grp = 0; grp < 6; ++grp) {
       const int kw = grp % 3;
       if (grp == 3) read_a(1);
 #pragma unroll
-      for (int k = 0; k < TNK; ++k) {
+      for (int k = 0; k < TK; ++k) {
 #pragma unroll
         for (int pr = 0; pr < sp_nprod(NS); ++pr)
 #pragma unroll
-          for (int n = 0; n < TNK; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
+          for (int n = 0; n < TN; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
         __builtin_amdgcn_sched_barrier(0);
         if (grp + 1 < 6) read_b(grp + 1, k);
         __builtin_amdgcn_sched_barrier(0);
@@ -2345,28 +2345,28 @@ __device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned c
 
   float* out = p.ws + (size_t)chunk * p.Cout * 9 * p.Cin;
   const int row9 = 9 * p.Cin;
-  const int obase = ((n0 + wn * 16 * TNK + 4 * g) * 9 + kh * 3) * p.Cin + k0 + wk * 16 * TNK + li;
+  const int obase = ((n0 + wn * 16 * TN + 4 * g) * 9 + kh * 3) * p.Cin + k0 + wk * 16 * TK + li;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int n = 0; n < TNK; ++n)
+    for (int n = 0; n < TN; ++n)
 #pragma unroll
-      for (int k = 0; k < TNK; ++k)
+      for (int k = 0; k < TK; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
 }
 
-template <int NS, int TNK, int WN, int WK>
+template <int NS, int TN, int TK, int WN, int WK>
 __global__ __launch_bounds__(192 * WN * WK) void wgrad9_wide_group_kernel(Wgrad9Group grp) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9WideLds<NS, TNK, WN, WK>::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9WideLds<NS, TN, TK, WN, WK>::BYTES];
   const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int gi = 0;
   while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
   const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
   const Wgrad9Args& p = grp.a[gi];
-  const int npairs = (p.Cout / (16 * TNK * WN)) * (p.Cin / (16 * TNK * WK));
-  wgrad9_wide_body<NS, TNK, WN, WK>(p, lds, local % npairs, local / npairs);
+  const int npairs = (p.Cout / (16 * TN * WN)) * (p.Cin / (16 * TK * WK));
+  wgrad9_wide_body<NS, TN, TK, WN, WK>(p, lds, local % npairs, local / npairs);
 }
 
 // role-split kernels (fp16x2 only): 384 threads = three consumer + three producer waves, two image buffers.

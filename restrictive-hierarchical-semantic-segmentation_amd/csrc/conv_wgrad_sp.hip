@@ -27,10 +27,13 @@ int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipS
 #undef WGS
   return 1;
 }
-// the wide form (fp16x2): two output-channel tiles of 48 per block share one x patch (96 x 48 block tile, six waves)
+// six-wave forms (fp16x2).  kind 1: two output-channel tiles of 48 per block share one x patch (96 x 48 block tile);
+// kind 2: the 64 x 64 tile pair of the one-pair-per-block kernel, its input channels split over two waves per kernel row
+// (4 x 2 tiles and 96 accumulator registers per wave instead of 4 x 4 and 192)
 int launch_wgrad9_wide(int kind, const Wgrad9Group& g, int nblocks, hipStream_t st) {
-  if (kind != 1) return HRSEG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 3, 2, 1>), dim3(nblocks), dim3(384), 0, st, g);
+  if (kind == 1) hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 3, 3, 2, 1>), dim3(nblocks), dim3(384), 0, st, g);
+  else if (kind == 2) hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 4, 2, 1, 2>), dim3(nblocks), dim3(384), 0, st, g);
+  else return HRSEG_ERR_UNSUPPORTED;
   HRSEG_LAUNCH_CHECK("wgrad9_wide");
   return 0;
 }

@@ -363,3 +363,34 @@ def test_wide_wgrad9_matches_the_one_pair_per_block_kernels(n):
         wr = torch.zeros(c, c, 3, 3, requires_grad=True)
         F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
         assert _rel((a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_six_wave_form_of_the_64_channel_wgrad9_bit_identical_to_the_three_wave_kernel(n):
+    """64-channel tilings (UNet, the HRNet stem stage): the six-wave form (opt-in, hrseg_tune wgrad9_split4=1) splits every kernel row's 4 x 4 tiles over two waves;
+    tile walk, pixel chunks, per-accumulator product order and the ordered reduce are those of wgrad9_sp_group_kernel4, so the
+    gradients must be IDENTICAL bit for bit (hrseg_tune wgrad9_split4=0 runs the three-wave kernel)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["fp16x2"]
+    g = torch.Generator().manual_seed(60 + n)
+    cfg = [(64, 128, 37, 45), (128, 64, 18, 23), (256, 256, 9, 12)][:n]
+    xs = [torch.randn(3, h, w, ci, generator=g).cuda() for ci, co, h, w in cfg]
+    dys = [(torch.randn(3, h, w, co, generator=g) * 1e-3).cuda() for ci, co, h, w in cfg]
+    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
+    base = [torch.randn(co, 9, ci, generator=g).cuda() for ci, co, h, w in cfg]
+    outs = {}
+    try:
+        for split in (1, 0):
+            _lib.tune(wgrad9_split4=split)
+            dws = [b.clone() for b in base]
+            _lib.launch_count(None, reset=True)
+            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
+            assert _lib.launch_count("wgrad9") == 1 and _lib.launch_count("wgrad9_wide") == split
+            outs[split] = dws
+    finally:
+        _lib.tune(wgrad9_split4=0)           # (the default: measured slower on the UNet step)
+    for a, b, x, dy, b0, (ci, co, h, w) in zip(outs[1], outs[0], xs, dys, base, cfg):
+        assert torch.equal(a, b), "six-wave and three-wave weight gradients differ"
+        wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        F.conv2d(x.permute(0, 3, 1, 2).cpu(), wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
+        assert _rel((a - b0).view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
