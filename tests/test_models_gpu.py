@@ -88,8 +88,8 @@ def _golden_body(name, model, mode="auto"):
     scale = np.maximum(ref, 1e-2 * ref.max())
     worst = np.argmax(np.abs(norms - ref) / scale)
     # outputs, losses and BN buffers above are held at 1e-3 in every mode.  Gradient NORMS of the earliest layers sit on the
-    # fp32 noise floor of these 32..64-pixel nets (2 x 2-pixel lowest branch, BN over 8 samples; tests/diagnostics/
-    # grad_noise.py: the CPU-fp32 reference is ~1e-2 from an fp64 evaluation there): 5e-3 for the default routing and the
+    # fp32 noise floor of these 32..64-pixel nets (2 x 2-pixel lowest branch, BN over 8 samples; tests/
+    # test_grad_noise_gpu.py asserts it: the CPU-fp32 reference is ~1e-2 from an fp64 evaluation there): 5e-3 for the default routing and the
     # exact-fp32 kernels, 1e-2 where every layer is forced onto the split-precision kernels with their split-K atomics
     # (observed: 7.4e-3 on stem.1.weight of hrnet_flat_tl_64 in one run of four)
     bar = 1e-2 if mode in ("fp16x2", "auto_ws") else 5e-3
@@ -99,7 +99,7 @@ def _golden_body(name, model, mode="auto"):
             got = named[key[6:]].grad.cpu().numpy()
             # head / FiLM gradients are a few ops from the loss; the first conv's sits behind every
             # BN/ReLU of the net, where fp32 evaluations differ from each other by ~1e-2 already
-            # (tests/diagnostics/grad_noise.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
+            # (tests/test_grad_noise_gpu.py: CPU-fp32 and GPU are equally far from an fp64 evaluation)
             tol = 5e-2 if key[6:].startswith(("stem", "inc0")) else 5e-3
             # absolute floor 2e-6: a head bias gradient is a sum over all pixels that cancels almost completely (the two-class
             # head of hrnet_hier_ext_62: +-8.9e-6 from terms of ~1e-3), so its value carries the rounding of that sum --
