@@ -185,6 +185,7 @@ static long patch_tiles(const IgemmArgs& a, int wtn) {
 static int g_sp_ws = 1;                 // hrseg_tune "sp_ws": 0 = never use the wave-specialised body
 static int g_ws_n48 = 1;                // hrseg_tune "sp_ws_n48": 0 = 48-channel tilings stay on the block-synchronous kernels
 static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile padding accepted, percent of the image
+static int g_ws_bf16 = 1;               // hrseg_tune "sp_ws_bf16": 0 = the bf16 arithmetic (one piece, one product) stays off the wave-specialised kernels
 static unsigned char* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 static int g_scratch_device = -1;       // the device that was current when the buffer was attached: launches on another one do not use it
@@ -274,18 +275,19 @@ static int ws_kind(const IgemmArgs& a) {
   if ((kind == 1 || kind == 4) && !g_ws_n48) return 0;
   return kind;
 }
-static size_t ws_image_bytes(const IgemmArgs& a, int kind) {
+static size_t ws_image_bytes(const IgemmArgs& a, int kind, int ns) {      // ns = 4: two fp16 pieces per weight, 1: one bf16 piece
   const int wtn = WS_WTN[kind], cs = WS_CS[kind];
-  return (size_t)(a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2) * (size_t)(2 * 16 * wtn * 64);
+  return (size_t)(a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2) * (size_t)((ns == 4 ? 2 : 1) * 16 * wtn * 64);
 }
 // writes the weight images of n problems (sets a[i].wimg) with one launch; false: no scratch space
-static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st) {
+static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st, int ns) {
   WeightImageGroup g;
   g.n = n;
+  g.ns = ns;
   size_t off[MAXG], total = 0;
   for (int i = 0; i < n; ++i) {
     off[i] = total;
-    total += (ws_image_bytes(a[i], kinds[i]) + 255) & ~(size_t)255;
+    total += (ws_image_bytes(a[i], kinds[i], ns) + 255) & ~(size_t)255;
   }
   unsigned char* base = scratch_reserve(st, total);
   if (!base) return false;
@@ -305,20 +307,20 @@ static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   launch_weight_images(g, end, st);
   return true;
 }
-static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st) {
+static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st, int ns = 4) {
   ws_set_canvas(a, kind);
   const int ntotal = (int)ws_tiles(a, kind);
-  if (!ws_make_images(&a, &kind, 1, st)) return 1;
+  if (!ws_make_images(&a, &kind, 1, st, ns)) return 1;
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
   ++g_cnt[CNT_WS];
   g_cnt[CNT_WS_CANVAS] += a.cv_w1 > 0;
-  return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st);
+  return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st, ns);
 }
 // One launch for several problems: the 256 persistent blocks are divided among the problems in proportion to their
 // slab counts, then blocks move from the problem that finishes first to the one that finishes last while that helps.
-static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st) {
+static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st, int ns = 4) {
   IgemmGroup g;
   g.n = n;
   long cost[MAXG], ntot[MAXG], total = 0;
@@ -353,7 +355,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     --blocks[lo];
     ++blocks[hi];
   }
-  if (!ws_make_images(a, kinds, n, st)) return 1;
+  if (!ws_make_images(a, kinds, n, st, ns)) return 1;
   int end = 0;
   for (int i = 0; i < n; ++i) {
     const int per = ceil_div((int)ntot[i], blocks[i]);
@@ -366,7 +368,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     g_cnt[CNT_WS_CANVAS] += a[i].cv_w1 > 0;
   }
   ++g_cnt[CNT_WS_GROUP];
-  return launch_ws_group_kernel(g, flip, st);
+  return launch_ws_group_kernel(g, flip, st, ns);
 }
 
 static int g_sp_img = 1;               // hrseg_tune "sp_img": 0 = the block-synchronous patch body splits its weights on the fly
@@ -383,7 +385,7 @@ static int launch_patch_sp(int ns, const IgemmArgs& a_in, int wtn, int cs, hipSt
   IgemmArgs a = a_in;
   if (ns == 4 && g_sp_img) {      // pre-split weights where an image layout exists for the tiling (else on the fly)
     int kind = (wtn == 3 && cs == 3) ? 1 : (wtn == 6 && cs == 3) ? 2 : (wtn == 4 && cs == 4) ? 3 : 0;
-    if (kind) ws_make_images(&a, &kind, 1, st);      // (no scratch space: a.wimg stays null)
+    if (kind) ws_make_images(&a, &kind, 1, st, 4);      // (no scratch space: a.wimg stays null)
   }
   ++g_cnt[CNT_PATCH_SP];
   return launch_patch_sp_kernel(ns, a, wtn, cs, flip, blocks, ntotal, st);
@@ -442,9 +444,9 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
   precision = resolve_auto(a, precision);
   if (const int ns = sp_pieces(precision)) {
     const SpPlan pl = plan_sp(a);
-    if (ns == 4 && !g_sp_wtn) {
+    if ((ns == 4 || (ns == 1 && g_ws_bf16)) && !g_sp_wtn) {
       const int kind = ws_kind(a);
-      if (kind && ws_tiles(a, kind) >= g_ws_min_tiles && launch_ws_single(a, kind, st) == 0) return 0;
+      if (kind && ws_tiles(a, kind) >= g_ws_min_tiles && launch_ws_single(a, kind, st, ns) == 0) return 0;
     }
     if (const int cs = patch_cs(a, pl.wtn)) {
       const int rc = launch_patch_sp(ns, a, pl.wtn, cs, st);
@@ -483,7 +485,7 @@ static int launch_sp_group(int ns, const IgemmGroup& g_in, int wtm, int wtn, int
     int kinds[MAXG], idx[MAXG], m = 0;
     for (int i = 0; i < g.n; ++i)
       if (g.kind[i]) { im[m] = g.a[i]; kinds[m] = wtn == 3 ? 1 : 3; idx[m++] = i; }
-    if (m && ws_make_images(im, kinds, m, st))
+    if (m && ws_make_images(im, kinds, m, st, 4))
       for (int j = 0; j < m; ++j) g.a[idx[j]].wimg = im[j].wimg;
   }
   bool full = true;
@@ -573,6 +575,24 @@ static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStr
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
   if (precision == HRSEG_CONV_AUTO) return dispatch_igemm_group_auto(a, n, st);
   const int ns = sp_pieces(precision);
+  if (ns == 1 && g_ws_bf16 && g_sp_ws && scratch_usable() && !g_sp_wtn) {
+    // bf16 arithmetic (BASELINE configs[4]): the problems the wave-specialised body takes go out as one launch of its
+    // one-piece instance, the rest as before
+    IgemmArgs wsa[MAXG], rest[MAXG];
+    int kinds[MAXG], nw = 0, nr = 0;
+    for (int i = 0; i < n; ++i) {
+      IgemmArgs f = a[i];
+      if (finalize_args(f)) return 1;
+      const int k = ws_kind(f);
+      if (k && ws_tiles(f, k) >= g_ws_min_tiles) { wsa[nw] = f; kinds[nw++] = k; }
+      else rest[nr++] = a[i];
+    }
+    if (nw >= 1 && launch_ws_group(wsa, kinds, nw, st, 1) == 0) {
+      for (int i = 0; i < nr; ++i)
+        if (int e = dispatch_igemm(rest[i], precision, st)) return e < 0 ? e : HRSEG_ERR_LAUNCH;
+      return 0;
+    }
+  }
   int wtn = (a[0].N % 48 == 0) ? 3 : (a[0].N % 64 == 0) ? 4 : 0;
   const int kc = ns ? 1 : (a[0].K % 48 == 0) ? 3 : (a[0].K % 32 == 0) ? 2 : 1;
   if (!wtn) return 1;
@@ -1297,7 +1317,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

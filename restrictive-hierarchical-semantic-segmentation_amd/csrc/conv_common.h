@@ -112,8 +112,8 @@ int launch_spw_kernel(const IgemmArgs& a, int wtn, int ksplit, unsigned char* im
 int launch_sp_group_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, bool full, hipStream_t st);
 int launch_patch_sp_kernel(int ns, const IgemmArgs& a, int wtn, int cs, int flip, int blocks, int ntotal, hipStream_t st);  // conv_sp_patch.hip
 int launch_sp_pgroup_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, int cs, int flip, hipStream_t st);               // conv_sp_pgroup.hip
-int launch_ws_kernel(const IgemmArgs& a, int kind, int flip, int blocks, int ntotal, hipStream_t st);    // conv_ws.hip
-int launch_ws_group_kernel(const IgemmGroup& g, int flip, hipStream_t st);
+int launch_ws_kernel(const IgemmArgs& a, int kind, int flip, int blocks, int ntotal, hipStream_t st, int ns = 4);    // conv_ws.hip
+int launch_ws_group_kernel(const IgemmGroup& g, int flip, hipStream_t st, int ns = 4);
 int launch_weight_images(const struct WeightImageGroup& g, int nblocks, hipStream_t st);
 int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, int tiles, hipStream_t st);     // conv_wgrad_sp.hip
 int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st);

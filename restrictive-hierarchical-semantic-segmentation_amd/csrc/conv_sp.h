@@ -1408,10 +1408,10 @@ struct SpPatchWsLds {
 
 // weight image: for every (channel tile, K stage, slab) the WSTAGE bytes the LDS weight buffer holds for it; one
 // launch writes the images of all problems of a grouped launch
-template <int WTN, int CS>
+template <int NS, int WTN, int CS>
 __device__ __forceinline__ void sp_weight_image_body(const float* __restrict__ w, unsigned char* __restrict__ img, int K,
                                                      float wscale, int blk) {
-  using L = SpPatchLds<4, 8, WTN, CS>;
+  using L = SpPatchLds<NS, 8, WTN, CS>;
   constexpr int BN = 16 * WTN, WG = BN * 8, NU = 9 * CS, NSLAB = (NU + 1) / 2;
   const int nks = K / (16 * CS);
   const int slab = blk % NSLAB;
@@ -1426,15 +1426,16 @@ __device__ __forceinline__ void sp_weight_image_body(const float* __restrict__ w
       const int t = u / CS, c = u - t * CS;
       v = *reinterpret_cast<const f32x4*>(w + ((size_t)(nt * BN + n) * 9 + t) * K + ks * CS * 16 + c * 16 + 4 * gq);
     }
-    u32x2 pc[2];
-    sp_split4<4>(v, pc, wscale);
+    u32x2 pc[sp_np(NS)];
+    sp_split4<NS>(v, pc, wscale);
     const int o = n * 64 + lds_slot(n, gq) * 16 + unit * 8;
-    *reinterpret_cast<u32x2*>(dst + o) = pc[0];
-    *reinterpret_cast<u32x2*>(dst + L::WPIECE + o) = pc[1];
+#pragma unroll
+    for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(dst + q * L::WPIECE + o) = pc[q];
   }
 }
 struct WeightImageGroup {
   int n;
+  int ns;                  // 4: two fp16 pieces per weight (fp16x2), 1: one bf16 piece (bf16)
   int blk_end[MAXG];
   int kind[MAXG];          // channel tiling of the wave-specialised body (conv.hip: ws_kind)
   int K[MAXG];
@@ -1448,15 +1449,21 @@ __global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g
   while (gi + 1 < g.n && (int)blockIdx.x >= g.blk_end[gi]) ++gi;
   const int blk = blockIdx.x - (gi ? g.blk_end[gi - 1] : 0);
   const int kind = g.kind[gi];
-  if (kind == 2) sp_weight_image_body<6, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
-  else if (kind == 3) sp_weight_image_body<4, 4>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
-  else sp_weight_image_body<3, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+  if (g.ns == 1) {
+    if (kind == 2) sp_weight_image_body<1, 6, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+    else if (kind == 3) sp_weight_image_body<1, 4, 4>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+    else sp_weight_image_body<1, 3, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+    return;
+  }
+  if (kind == 2) sp_weight_image_body<4, 6, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+  else if (kind == 3) sp_weight_image_body<4, 4, 4>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
+  else sp_weight_image_body<4, 3, 3>(g.w[gi], g.img[gi], g.K[gi], g.wscale[gi], blk);
 }
 #endif
 
 template <int NS, int TH, int WTN, int CS, int FLIP>
 __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end) {
-  static_assert(NS == 4, "the wave-specialised body is the fp16x2 one");
+  static_assert(NS == 4 || NS == 1, "the wave-specialised body: fp16x2 (two pieces, three products) or bf16 (one piece, one product)");
   using L = SpPatchLds<NS, TH, WTN, CS>;
   constexpr int RPW = TH / 4, BN = 16 * WTN, PW = 18, PP = L::PP;
   // patch granules (16 bytes of fp32 = 4 channels): a round of the 256 producer threads covers PR whole pixels,
@@ -1528,7 +1535,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     const int pbase = prow0 * 32;
     constexpr int NP = sp_np(NS);
     constexpr int UNITS = RPW * NP + WTN * NP;             // fragment registers (8 halfs each) of a slab
-    constexpr int MM = WTN * RPW * 3;                      // MFMAs of a slab
+    constexpr int MM = WTN * RPW * sp_nprod(NS);           // MFMAs of a slab
     // fragment r of slab `slab` (compile-time) -> register set
     auto read_unit = [&](int slab, int wboff, int pbuf, int r, bf16x8 (&xf)[RPW][NP], bf16x8 (&wf)[WTN][NP]) {
       if (r < RPW * NP) {
@@ -1632,15 +1639,19 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           const int npb = (s + 1 < NSLAB) ? pb : pb ^ 1;
           int k = 0;
 #pragma unroll
-          for (int pr = 0; pr < 3; ++pr) {
+          for (int pr = 0; pr < sp_nprod(NS); ++pr) {
 #pragma unroll
             for (int n = 0; n < WTN; ++n) {
 #pragma unroll
               for (int m = 0; m < RPW; ++m) {
                 // products in the order of sp_mma (w1 x0, w0 x1, w0 x0) per accumulator, WTN*RPW MFMAs apart
-                const f16x8 wv = __builtin_bit_cast(f16x8, wfr[s & 1][n][pr == 0 ? 1 : 0]);
-                const f16x8 xv = __builtin_bit_cast(f16x8, xfr[s & 1][m][pr == 1 ? 1 : 0]);
-                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[n][m], 0, 0, 0);
+                if (NS == 4) {
+                  const f16x8 wv = __builtin_bit_cast(f16x8, wfr[s & 1][n][pr == 0 ? NP - 1 : 0]);
+                  const f16x8 xv = __builtin_bit_cast(f16x8, xfr[s & 1][m][pr == 1 ? NP - 1 : 0]);
+                  acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[n][m], 0, 0, 0);
+                } else {
+                  acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s & 1][n][0], xfr[s & 1][m][0], acc[n][m], 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = k * UNITS / MM; r < (k + 1) * UNITS / MM; ++r)
                   read_unit(nslab, wb1, npb, r, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
@@ -1825,11 +1836,11 @@ __global__ __launch_bounds__(512) void igemm_patch_ws_kernel(IgemmArgs p, int nt
 // grouped form: every problem runs the wave-specialised body on its own range of persistent blocks (grp.tiles[g]
 // blocks for problem g, grp.ksplit[g] = its tile count), with its own channel tiling: kind 1 = 48 channels x 48-channel
 // K stages, 2 = 96 x 48, 3 = 64 x 64, 4 = 48 x 48 on 16-row tiles
-template <int FLIP>
+template <int NS, int FLIP>
 __global__ __launch_bounds__(512) void igemm_patch_ws_group_kernel(IgemmGroup grp) {
-  static_assert(SpPatchWsLds<4, 16, 3, 3>::BYTES >= SpPatchWsLds<4, 8, 4, 4>::BYTES &&
-                SpPatchWsLds<4, 16, 3, 3>::BYTES >= SpPatchWsLds<4, 8, 6, 3>::BYTES, "LDS of the largest variant");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchWsLds<4, 16, 3, 3>::BYTES];
+  static_assert(SpPatchWsLds<NS, 16, 3, 3>::BYTES >= SpPatchWsLds<NS, 8, 4, 4>::BYTES &&
+                SpPatchWsLds<NS, 16, 3, 3>::BYTES >= SpPatchWsLds<NS, 8, 6, 3>::BYTES, "LDS of the largest variant");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchWsLds<NS, 16, 3, 3>::BYTES];
   int gi = 0;
   while (gi + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[gi]) ++gi;
   const int local = blockIdx.x - (gi ? grp.blk_end[gi - 1] : 0);
@@ -1837,10 +1848,10 @@ __global__ __launch_bounds__(512) void igemm_patch_ws_group_kernel(IgemmGroup gr
   const int chunk = (ntotal + nblk - 1) / nblk;
   const int first = local * chunk, end = min(first + chunk, ntotal);
   const int kind = grp.kind[gi];
-  if (kind == 1) igemm_patch_ws_body<4, 8, 3, 3, FLIP>(grp.a[gi], lds, first, end);
-  else if (kind == 2) igemm_patch_ws_body<4, 8, 6, 3, FLIP>(grp.a[gi], lds, first, end);
-  else if (kind == 3) igemm_patch_ws_body<4, 8, 4, 4, FLIP>(grp.a[gi], lds, first, end);
-  else igemm_patch_ws_body<4, 16, 3, 3, FLIP>(grp.a[gi], lds, first, end);
+  if (kind == 1) igemm_patch_ws_body<NS, 8, 3, 3, FLIP>(grp.a[gi], lds, first, end);
+  else if (kind == 2) igemm_patch_ws_body<NS, 8, 6, 3, FLIP>(grp.a[gi], lds, first, end);
+  else if (kind == 3) igemm_patch_ws_body<NS, 8, 4, 4, FLIP>(grp.a[gi], lds, first, end);
+  else igemm_patch_ws_body<NS, 16, 3, 3, FLIP>(grp.a[gi], lds, first, end);
 }
 
 // grouped launch whose problems run either body (the parallel HRNet branches: the wide high-resolution

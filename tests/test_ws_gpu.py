@@ -394,3 +394,72 @@ def test_six_wave_form_of_the_64_channel_wgrad9_bit_identical_to_the_three_wave_
         wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
         F.conv2d(x.permute(0, 3, 1, 2).cpu(), wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
         assert _rel((a - b0).view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
+
+
+BF16_TOL = 6e-3        # operands rounded to bf16 (2^-9 each), fp32 accumulation: 2.2-2.8e-3 measured on these shapes
+
+
+@pytest.mark.parametrize("case", [WS_CASES[0], WS_CASES[1], WS_CASES[3], WS_CASES[6], WS_CASES[8]])
+def test_bf16_instance_of_the_wave_specialised_body(case):
+    """BASELINE configs[4] arithmetic (conv_dtype 'bf16': one bf16 piece per operand, one MFMA product) on the
+    wave-specialised kernels: forward, data gradient and accumulating data gradient against the block-synchronous /
+    im2col bf16 kernels (hrseg_tune sp_ws_bf16=0; bit-identical where the halo-patch body takes the problem) and torch"""
+    from hrseg_amd import _lib, ops
+    cin, cout, H, W, B, n48, exact = case
+    _lib.tune(sp_ws_n48=n48)
+    pr = _lib.CONV_PRECISION["bf16"]
+    g = torch.Generator().manual_seed(sum(case[:5]) + 1)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, bias, stride=1, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd, wd, dyd, bd = _nhwc(x), w.permute(0, 2, 3, 1).contiguous().cuda().reshape(cout, 9, cin), _nhwc(dy), bias.cuda()
+    wt = ops.weight_transpose(wd, cout, 9, cin)
+    base = torch.randn(xd.shape, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run():
+        _lib.launch_count(None, reset=True)
+        y = ops.conv_fwd(xd, wd, bd, 3, 1, prec=pr)
+        dx = ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, prec=pr)
+        acc = ops.conv_dgrad(dyd, wt, xd.shape, 3, 1, out=base.clone(), accumulate=True, prec=pr)
+        return (y, dx, acc), _lib.launch_count("ws")
+
+    try:
+        _lib.tune(sp_ws_bf16=1)
+        on, n_on = run()
+        _lib.tune(sp_ws_bf16=0)
+        off, n_off = run()
+    finally:
+        _lib.tune(sp_ws_bf16=1)
+    assert n_on == 3 and n_off == 0, (n_on, n_off)
+    for a, b, what in zip(on, off, ("forward", "data gradient", "accumulating data gradient")):
+        assert not exact or torch.equal(a, b), f"{what}: wave-specialised and block-synchronous bf16 results differ"
+        assert _rel(a, b) < 1e-5 if exact else _rel(a, b) < BF16_TOL, what
+    assert _rel(on[0].permute(0, 3, 1, 2), y_ref) < BF16_TOL
+    assert _rel(on[1].permute(0, 3, 1, 2), xr.grad) < BF16_TOL
+    assert _rel((on[2] - base).permute(0, 3, 1, 2), xr.grad) < 2 * BF16_TOL
+
+
+def test_bf16_group_launch_on_the_wave_specialised_body():
+    """the four parallel branches under conv_dtype 'bf16' as one grouped call: one wave-specialised launch (bf16 instance),
+    every branch equal to its own single launch and to the exact-fp32 kernels within the bf16 tolerance"""
+    from hrseg_amd import _lib, ops
+    chans, xs, ws = _branches(8, seed=17)
+    pr = _lib.CONV_PRECISION["bf16"]
+    _lib.launch_count(None, reset=True)
+    ys = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=pr)
+    assert _lib.launch_count("ws_group") == 1
+    for i in range(4):
+        single = ops.conv_fwd(xs[i], ws[i], None, 3, 1, prec=pr)
+        assert torch.equal(ys[i], single), f"branch {i}: grouped and single bf16 launches differ"
+        assert _rel(ys[i], ops.conv_fwd(xs[i], ws[i], None, 3, 1, prec=0)) < BF16_TOL
+    dys = [torch.randn_like(x) for x in xs]
+    wts = [ops.weight_transpose(w, c, 9, c) for w, c in zip(ws, chans)]
+    _lib.launch_count(None, reset=True)
+    dxs = ops.conv_dgrad_group(dys, wts, [x.shape for x in xs], 3, 1, [None] * 4, [False] * 4, prec=pr)
+    assert _lib.launch_count("ws_group") == 1
+    for i in range(4):
+        assert _rel(dxs[i], ops.conv_dgrad(dys[i], wts[i], xs[i].shape, 3, 1, prec=0)) < BF16_TOL
