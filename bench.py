@@ -182,7 +182,7 @@ def probe_dominant_kernel(device, batch, size, conv_dtype="auto"):
     flops = sum(sum(fl[:n]) * r for n, r in mix) / launches
     ach = flops / t / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-    name = "igemm_patch_ws_group_kernel<0>"
+    name = "igemm_patch_ws_group_kernel<4, 0>"          # <arithmetic (4 = fp16x2), tap geometry (0 = forward)>
     traffic, src = pmc_value(name, "traffic")
     busy, bsrc = pmc_value(name, "mfma_busy")
     return {"bound": "mfma",
