@@ -136,7 +136,8 @@ long hrseg_launch_count(const char* family, int reset);
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
  * wgrad_group_min, wgrad_group_max (fp32 kernels); sp_wtm, sp_wtn, sp_ksplit, sp_patch, sp_persist (split-precision
  * kernels); sp_ws (0: never use the wave-specialised 3x3 kernels), sp_ws_n48 (0: 48-channel tilings stay on the
- * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_bf16 (0: the BF16 arithmetic stays off the wave-specialised kernels), sp_ws_canvas (0: tile every image on its own, never the batch as one
+ * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_bf16 (0: the BF16 arithmetic stays off the wave-specialised kernels), small_cin3 (0: the 3-channel first layer on the generic
+ * Cin <= 8 kernels), sp_ws_canvas (0: tile every image on its own, never the batch as one
  * canvas), sp_img (0: block-synchronous kernels
  * split their weights on the fly); wgrad9, wgrad9_blocks, wgrad9_wide, wgrad9_split4 (nine-tap weight gradient; 1: the wide form resp. the six-wave form of the
  * 64-channel tiling, both measured slower, default 0); wgrad_group_sp (0: grouped tap-per-block

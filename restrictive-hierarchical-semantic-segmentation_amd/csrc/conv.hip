@@ -182,6 +182,7 @@ static long patch_tiles(const IgemmArgs& a, int wtn) {
 // the caller's, as everywhere in this ABI).  It is cut into eight regions, one per stream that launches convolutions,
 // each a ring: an image is written and read by kernels of ONE stream, in order, so reusing a slot after the ring
 // wraps needs no synchronisation.  Without a scratch buffer the path is simply not taken.
+extern int g_small_cin3;                // conv_small.hip
 static int g_sp_ws = 1;                 // hrseg_tune "sp_ws": 0 = never use the wave-specialised body
 static int g_ws_n48 = 1;                // hrseg_tune "sp_ws_n48": 0 = 48-channel tilings stay on the block-synchronous kernels
 static int g_ws_waste = 200;            // hrseg_tune "sp_ws_waste": tile padding accepted, percent of the image
@@ -1317,7 +1318,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -3,6 +3,8 @@
 // channel capacity (the 3-channel layer keeps its 4-wide vectors).
 #include "conv_common.h"
 
+int g_small_cin3 = 1;       // hrseg_tune "small_cin3": 0 = the 3-channel 3x3 first layer stays on the generic Cin <= 8 kernels
+
 // y[b,oy,ox,co] = bias[co] + sum_{t,ci} x[b, oy*s+kh-1, ox*s+kw-1, ci] * w[co][t][ci]
 // one thread = one output pixel x 16 channels; weights of the block's 64 channels in LDS.
 template <int CMAX>
@@ -50,6 +52,133 @@ __global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __
       if (res) v += res[(size_t)m * ldr + co];
       yp[j] = relu ? fmaxf(v, 0.f) : v;
     }
+  }
+}
+
+// The actual first layer (3 input channels, 3x3): thread = 4 output channels of one pixel, its 4 x 27 weights in REGISTERS for
+// the whole pixel loop (the generic kernel above reads one weight from LDS per FMA and stores 16 scattered floats per thread:
+// 264 us for the 197 MB the HRNet stem writes, 6x the time of those bytes).  A wave covers 4 pixels x 64 channels: 256
+// contiguous bytes stored per pixel.  Same accumulation order per output element as the generic kernel (tap-major, channel-minor).
+__global__ __launch_bounds__(256) void conv_cin3_k3_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                               int B, int Hi, int Wi, int Ho, int Wo, int stride,
+                                                               const float* __restrict__ res, int ldr, int relu) {
+  const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int co = blockIdx.y * 64 + 4 * cq;
+  float wr[27][4];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[k][j] = w[(size_t)(co + j) * 27 + k];          // [co][t][ci], Cin = 3
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
+  const int M = B * Ho * Wo, hw = Ho * Wo;
+  for (int m = blockIdx.x * 16 + pl; m < M; m += gridDim.x * 16) {
+    const int b = m / hw, rem = m - b * hw;
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy * stride + kh - 1;
+      const bool rok = (unsigned)iy < (unsigned)Hi;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox * stride + kw - 1;
+        const bool ok = rok & ((unsigned)ix < (unsigned)Wi);
+        const float* xp = x + ((size_t)(b * Hi + (ok ? iy : 0)) * Wi + (ok ? ix : 0)) * ldx;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float xv = ok ? xp[ci] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, wr[(kh * 3 + kw) * 3 + ci][j], acc[j]);
+        }
+      }
+    }
+    f32x4 v = acc + bv;
+    if (res) v += *reinterpret_cast<const f32x4*>(res + (size_t)m * ldr + co);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + co) = v;
+  }
+}
+
+// weight gradient of the same layer: block = 64 output channels x a pixel range, 64-pixel stages through LDS as in the
+// generic kernel; thread = (output channel, quarter of the stage's pixels) with ALL 27 (tap, channel) sums in registers: per
+// pixel one dy read and nine 16-byte broadcast reads of the staged taps for 27 FMAs (generic kernel: 13 LDS reads per 12 FMAs).
+// The four quarters meet in LDS in a fixed order; one atomic add per weight and block.
+__global__ __launch_bounds__(256) void conv_cin3_k3_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                                 int lddy, float* __restrict__ dw, int B, int Hi, int Wi, int Ho,
+                                                                 int Wo, int stride, int pix_per_block) {
+  constexpr int P = 64;
+  __shared__ __attribute__((aligned(16))) float dys[P][64];
+  __shared__ __attribute__((aligned(16))) float xs[P][9][4];
+  __shared__ float red[3][64][28];                      // quarters 1..3 of the block's sums ([28]: bank spread)
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * 64, col = tid & 63, pg = tid >> 6;
+  const int M = B * Ho * Wo, hw = Ho * Wo;
+  const int lo = blockIdx.x * pix_per_block;
+  const int hi = min(lo + pix_per_block, M);
+  float acc[9][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[t][c] = 0.f;
+  for (int s0 = lo; s0 < hi; s0 += P) {
+#pragma unroll
+    for (int r = 0; r < (P * 16) / 256; ++r) {            // dy tile: thread -> (pixel j>>4, 4 channels (j&15)*4)
+      const int j = tid + 256 * r;
+      const int pp = j >> 4, c4 = (j & 15) * 4;
+      const int m = s0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * lddy + co0 + c4);
+      *reinterpret_cast<f32x4*>(&dys[pp][c4]) = v;
+    }
+    for (int j = tid; j < P * 9; j += 256) {              // input taps: item -> (pixel, tap)
+      const int pp = j / 9, t = j - pp * 9;
+      const int m = s0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < hi) {
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const int iy = oy * stride + t / 3 - 1, ix = ox * stride + t % 3 - 1;
+        if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+          const float* xp = x + ((size_t)(b * Hi + iy) * Wi + ix) * ldx;
+          v = f32x4{xp[0], xp[1], xp[2], 0.f};
+        }
+      }
+      *reinterpret_cast<f32x4*>(&xs[pp][t][0]) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < P / 4; ++q) {
+      const int pp = pg * (P / 4) + q;
+      const float g = dys[pp][col];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[pp][t][0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[t][c] = fmaf(g, xv[c], acc[t][c]);
+      }
+    }
+    __syncthreads();
+  }
+  if (pg > 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) red[pg - 1][col][t * 3 + c] = acc[t][c];
+  }
+  __syncthreads();
+  if (pg == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = ((acc[t][c] + red[0][col][t * 3 + c]) + red[1][col][t * 3 + c]) + red[2][col][t * 3 + c];
+        atomicAdd(dw + ((size_t)(co0 + col) * 9 + t) * 3 + c, v);
+      }
   }
 }
 
@@ -196,6 +325,13 @@ void launch_small_cin_fwd(const float* x, const float* w, const float* bias, flo
   const float* res = s->residual;
   const int ldr = s->ldr, relu = s->relu;
   const long M = (long)s->B * s->Ho * s->Wo;
+  if (s->Cin == 3 && s->ksize == 3 && s->Cout % 64 == 0 && s->ldy % 4 == 0 && (!res || ldr % 4 == 0) && M < (1L << 31) && g_small_cin3) {
+    long gx = ceil_div(M, 16);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(conv_cin3_k3_fwd_kernel, dim3((unsigned)gx, s->Cout / 64), dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B,
+                       s->Hi, s->Wi, s->Ho, s->Wo, s->stride, res, ldr, relu);
+    return;
+  }
   dim3 grid(ceil_div(M, 64), ceil_div(s->Cout, 64));
   if (s->Cin <= 4)
     hipLaunchKernelGGL(conv_small_cin_fwd_kernel<4>, grid, dim3(256), 0, st, x, s->ldx, w, bias, y, s->ldy, s->B, s->Hi, s->Wi,
@@ -206,6 +342,11 @@ void launch_small_cin_fwd(const float* x, const float* w, const float* bias, flo
 }
 void launch_small_cin_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s, int ppb, hipStream_t st) {
   const long M = (long)s->B * s->Ho * s->Wo;
+  if (s->Cin == 3 && s->ksize == 3 && s->Cout % 64 == 0 && s->ldy % 4 == 0 && M < (1L << 31) && g_small_cin3) {
+    hipLaunchKernelGGL(conv_cin3_k3_wgrad_kernel, dim3(ceil_div(M, ppb), s->Cout / 64), dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw,
+                       s->B, s->Hi, s->Wi, s->Ho, s->Wo, s->stride, ppb);
+    return;
+  }
   dim3 grid(ceil_div(M, ppb), ceil_div(s->Cout, 64));
   if (s->Cin <= 4)
     hipLaunchKernelGGL(conv_small_cin_wgrad_kernel<4>, grid, dim3(256), 0, st, x, s->ldx, dy, s->ldy, dw, s->B, s->Hi, s->Wi,

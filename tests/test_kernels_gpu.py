@@ -750,3 +750,38 @@ def test_metric_vectors_kernel_equals_the_per_level_tensor_arithmetic(ops):
     assert vec.shape == (5, 4 + 4 + 7 + 2)
     for i, k in enumerate(METRIC_NAMES):
         assert torch.equal(vec[i], torch.cat(want[k])), k
+
+
+@pytest.mark.parametrize("stride,H,W,B,cout", [(2, 61, 77, 3, 64), (1, 33, 46, 2, 64), (2, 300, 301, 2, 64), (1, 19, 20, 2, 128)])
+def test_three_channel_first_layer_kernels_equal_the_generic_ones(ops, stride, H, W, B, cout):
+    """the stem's 3 -> 64 3x3 convolution has kernels of its own (weights in registers, 16-byte stores; 27 sums per thread in
+    the weight gradient): the forward -- bias, residual and ReLU included -- must equal the generic Cin <= 8 kernel bit for bit
+    (same accumulation order; hrseg_tune small_cin3=0 runs the generic one), the weight gradient agrees to fp32 summation
+    order, and both match torch"""
+    from hrseg_amd import _lib
+    g = torch.Generator().manual_seed(H + W + stride)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = (torch.randn(cout, 3, 3, 3, generator=g) / 5).requires_grad_(True)
+    bias = torch.randn(cout, generator=g)
+    y_ref = F.conv2d(x, w, bias, stride=stride, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    res = torch.randn(y_ref.shape, generator=g)
+    xd, wd, dyd, rd = nhwc(x), store(w.detach()), nhwc(dy), nhwc(res)
+    out = {}
+    try:
+        for new in (1, 0):
+            _lib.tune(small_cin3=new)
+            y = ops.conv_fwd(xd, wd, bias.cuda(), 3, stride)
+            yr = ops.conv_fwd(xd, wd, bias.cuda(), 3, stride, residual=rd, relu=True)
+            dw = torch.zeros_like(wd)
+            ops.conv_wgrad(xd, dyd, dw, 3, stride)
+            ops.conv_wgrad(xd, dyd, dw, 3, stride)
+            out[new] = (y, yr, dw)
+    finally:
+        _lib.tune(small_cin3=1)
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
+    assert rel(nchw(out[1][0]), y_ref) < 1e-5
+    assert rel(nchw(out[1][1]), torch.relu(y_ref.detach() + res)) < 1e-5
+    assert rel(out[1][2], out[0][2]) < 2e-5
+    assert rel(out[1][2].view(cout, 3, 3, 3).permute(0, 3, 1, 2).cpu(), 2 * w.grad) < 5e-5

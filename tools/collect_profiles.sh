@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the profile set of profiles/README.md on a GPU box: kernel stats (default two-stream run and single-stream),
 # HBM traffic and MFMA-busy PMC passes (counters in their own runs, --kernel-trace only), the bench line.
-#   bash tools/collect_profiles.sh <tag>        -> gpurun_out/profiles_<tag>/
+#   [HRSEG_COMMIT=<short hash>] bash tools/collect_profiles.sh <tag>        -> gpurun_out/profiles_<tag>/
 set -e -o pipefail
 tag=${1:-rXX}
 out=gpurun_out/profiles_$tag
@@ -30,7 +30,9 @@ python3 - <<PY > $out/${tag}_meta.json
 import json, sys
 sys.path.insert(0, ".")
 import bench
-print(json.dumps({"csrc_digest": bench._csrc_digest(), "commit": open("gpurun_out/.head").read().strip() if __import__("os").path.exists("gpurun_out/.head") else "?"}))
+import os
+commit = os.environ.get("HRSEG_COMMIT") or (open("gpurun_out/.head").read().strip() if os.path.exists("gpurun_out/.head") else "?")
+print(json.dumps({"csrc_digest": bench._csrc_digest(), "commit": commit}))
 PY
 rm -rf $out/ks $out/ks1 $out/ks2 $out/pf $out/pw $out/pm
 ls -la $out
