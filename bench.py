@@ -72,6 +72,10 @@ def parse():
                                                           "of issuing the kernels from Python; measured slightly slower "
                                                           "than eager issue + weight-gradient side stream on MI355X")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every step through the Python engine (train.train_step) instead of replaying the recorded "
+                         "launch tape of the step (train.TapedTrainStep, the default: same kernels, same arguments, same "
+                         "streams, a fraction of the host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--host-time", action="store_true", help="also log the host-side issue time of one step")
@@ -456,14 +460,31 @@ def main():
     model.train()
     level_loss = []
 
-    graphed = None
+    from hrseg_amd import _lib
+    FAMILIES = ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "sp_wide", "f32", "f32_group", "wgrad9",
+                "wgrad_sp", "wgrad_sp_group", "wgrad_sp_wide", "wgrad_f32", "wgrad_f32_group", "small_cin")
+    state = {"graphed": None, "taped": None}
     if world == 1 and args.graph:
-        graphed = T.GraphedTrainStep(model, opt, loss_fns, ns, tree, x, t, warmup=1)
+        state["graphed"] = T.GraphedTrainStep(model, opt, loss_fns, ns, tree, x, t, warmup=1)
+
+    def launch_mode():
+        return "hipGraph replay" if state["graphed"] is not None else ("eager" if args.eager else "launch tape replay")
+
+    def retape():
+        """(re)record the launch tape of the step for the model's current configuration; the old tape's pool is released"""
+        if args.eager or state["graphed"] is not None:
+            return
+        state["taped"] = None
+        torch.cuda.empty_cache()
+        state["taped"] = T.TapedTrainStep(model, opt, loss_fns, ns, tree, x, t)
 
     def body(xd, td):
         """the batch body of train_epoch (train.py:179-248): step, metric vectors, ONE device->host copy"""
-        if graphed is not None:
-            loss, cms = graphed(xd, td)
+        if state["taped"] is not None:
+            packed, _ = state["taped"](xd, td)
+            return state["taped"].unpack(packed.tolist())[0]
+        if state["graphed"] is not None:
+            loss, cms = state["graphed"](xd, td)
         else:
             loss, cms = T.train_step(model, opt, xd, td, loss_fns, ns, tree, level_loss)
         vec = T._metric_vectors(cms)
@@ -477,9 +498,25 @@ def main():
         return body(x_host.to(device, non_blocking=True), t_host.to(device, non_blocking=True))
 
     def step_async():
-        if graphed is not None:
-            return graphed(x, t)
+        if state["taped"] is not None:
+            return state["taped"](x, t)
+        if state["graphed"] is not None:
+            return state["graphed"](x, t)
         return T.train_step(model, opt, x, t, loss_fns, ns, tree, level_loss)
+
+    def host_issue():
+        """host time to ISSUE one step (no readback, nothing waited for) and the library's conv launches per step by kernel
+        family: says whether two lines of this report ran the same kernels, and whether a step is host- or GPU-bound"""
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            _lib.launch_count(None, reset=True)
+            th = time.perf_counter()
+            step_async()
+            ts.append(time.perf_counter() - th)
+            torch.cuda.synchronize()
+        counts = {f: _lib.launch_count(f, reset=True) for f in FAMILIES}
+        return round(1e3 * sorted(ts)[1], 2), {k: v for k, v in counts.items() if v}
 
     def log(msg):
         if rank == 0:
@@ -506,6 +543,7 @@ def main():
 
     log("model on %s, %d params; warmup %d, steps %d" % (device, sum(p.numel() for p in model.parameters()),
                                                           args.warmup, args.steps))
+    retape()                                  # (the recording run is a real train step on this batch)
     for i in range(args.warmup):
         tw = time.perf_counter()
         loss = step()
@@ -515,14 +553,8 @@ def main():
     dt, final_loss = timed(step, args.steps)
     dt_host, _ = timed(step_from_host, args.steps)
     dt_async, _ = timed(step_async, args.steps)
-    if args.host_time:
-        for _ in range(2):
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            step_async()
-            t_issue = time.perf_counter() - th
-            torch.cuda.synchronize()
-            log("host issue %.1f ms, step complete after %.1f ms" % (1e3 * t_issue, 1e3 * (time.perf_counter() - th)))
+    host_ms, launches = host_issue()
+    log("host issue %.1f ms per step (%s); conv launches per step %s" % (host_ms, launch_mode(), launches))
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
@@ -540,7 +572,7 @@ def main():
                                        "HRNet-W48" if args.model == "hrnet" else "UNet",
                                        "hierarchical" if hier else "flat", args.tree, args.size, args.size, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "launch": "hipGraph replay" if graphed is not None else "eager",
+                       "launch": launch_mode(),
                        "conv_arithmetic": CONV_ARITHMETIC.get(conv_dtype, conv_dtype),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
                        "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
@@ -549,6 +581,7 @@ def main():
                                      "note": "same body with the batch copied from pinned host memory inside the timed "
                                              "step (train.py:181); never the headline value"},
             "ms_per_step_no_readback": round(1e3 * dt_async / args.steps, 2),
+            "host_issue_ms": host_ms, "conv_launches_per_step": launches,
         }
         if gf is not None and args.size == 620:
             tf = ips * gf / 1e3
@@ -557,17 +590,21 @@ def main():
         log("timed: %.3f s for %d steps (resident), %.3f s (from host), %.3f s (no readback)" % (dt, args.steps, dt_host, dt_async))
         line["config"]["level_passes"] = ("sequential" if getattr(model, "sequential_passes", False) else
                                           "batched (one launch per layer for all L passes)") if hier else "n/a"
+        graphed = state["graphed"]
         if world == 1 and hier and graphed is None and not args.no_dedup_line:
             # NOT the headline number: the opt-in mode that runs the L bit-identical level passes once
             # (Models/models.py:_run).  Same result, 1/L of the backbone FLOPs executed -- reported apart.
             model.dedup_passes = True
+            retape()
             for _ in range(2):
                 step()
             td, _ = timed(step, args.steps)
+            hi, lc = host_issue()
             model.dedup_passes = False
             line["opt_in_dedup_passes"] = {
                 "value": round(args.batch * args.steps / td, 3), "unit": "images/s",
                 "ms_per_step": round(1e3 * td / args.steps, 2), "executed_backbone_passes_per_step": 1,
+                "host_issue_ms": hi, "conv_launches_per_step": lc,
                 "note": "explicit opt-in (model.dedup_passes / HRSEG_DEDUP_PASSES=1); the default and headline value "
                         "execute all L passes"}
             log("opt-in dedup passes: %.1f ms/step" % (1e3 * td / args.steps))
@@ -575,12 +612,15 @@ def main():
             # NOT the headline: bf16-input / fp32-accumulate convolutions (BASELINE configs[4] arithmetic), opt-in
             prev = model.conv_dtype
             model.conv_dtype = "bf16"
+            retape()
             for _ in range(2):
                 step()
             tb, _ = timed(step, args.steps)
+            hi, lc = host_issue()
             model.conv_dtype = prev
             line["opt_in_bf16_convs"] = {
                 "value": round(args.batch * args.steps / tb, 3), "unit": "images/s", "ms_per_step": round(1e3 * tb / args.steps, 2),
+                "host_issue_ms": hi, "conv_launches_per_step": lc,
                 "dtype": "bf16 inputs, fp32 accumulate (convolutions only; BN, loss, optimizer fp32)",
                 "note": "explicit opt-in (model.conv_dtype='bf16'): results differ from the fp32 reference beyond 1e-3"}
             log("opt-in bf16 convs: %.1f ms/step" % (1e3 * tb / args.steps))
@@ -589,12 +629,15 @@ def main():
             # figure to hold next to the headline, whose contractions run as fp16x2 splits
             prev = model.conv_dtype
             model.conv_dtype = "f32"
+            retape()
             for _ in range(2):
                 step()
             tf32, loss32 = timed(step, args.steps)
+            hi, lc = host_issue()
             model.conv_dtype = prev
             line["exact_f32_convs"] = {
                 "value": round(args.batch * args.steps / tf32, 3), "unit": "images/s", "ms_per_step": round(1e3 * tf32 / args.steps, 2),
+                "host_issue_ms": hi, "conv_launches_per_step": lc,
                 "dtype": "f32 (exact fp32 MFMA, v_mfma_f32_16x16x4_f32)", "final_loss": loss32,
                 "note": "model.conv_dtype='f32': every convolution on the exact-fp32 MFMA kernels; never the headline value"}
             if gf is not None and args.size == 620:
@@ -602,6 +645,8 @@ def main():
                 line["exact_f32_convs"].update(achieved_tflops=round(tfl, 2), peak=FP32_MFMA_PEAK_TFLOPS,
                                                frac=round(tfl / FP32_MFMA_PEAK_TFLOPS, 4))
             log("exact-fp32 convs: %.1f ms/step" % (1e3 * tf32 / args.steps))
+        state["taped"] = None                     # the probes below launch kernels directly; release the tape's pool
+        torch.cuda.empty_cache()
         if not args.no_probe:
             # the level passes run batched: every conv launch sees batch * L images
             n_pass = len(model.levels) if (hier and not getattr(model, "sequential_passes", False)) else 1

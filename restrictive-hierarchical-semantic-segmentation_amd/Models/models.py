@@ -65,6 +65,17 @@ class FiLM(nn.Module):
             return feats * gb[:, :f, None, None] + gb[:, f:, None, None]
 
 
+SMALL_CIN_MAX = 8       # csrc/conv_common.h HRSEG_SMALL_CIN_MAX: widest input of the direct (non-MFMA) first-layer kernels
+
+
+def _check_cond_stem_width(widths):
+    """concat_prev_logits: level L's first convolution reads cat(image, logits_{L-1}); it runs the direct Cin <= 8 kernels"""
+    for L, w in enumerate(widths, start=1):
+        if w > SMALL_CIN_MAX:
+            raise ValueError(f"concat_prev_logits: level {L} would encode {w} input channels (image + the logits of level "
+                             f"{L - 1}); the first-layer kernels take at most {SMALL_CIN_MAX}")
+
+
 def _store(p):
     return p._hr_store if hasattr(p, "_hr_store") else p.detach().contiguous()
 
@@ -173,10 +184,11 @@ class _Run:
         from ..engine import wgrad_stream
         side = wgrad_stream(flat.grad.device)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            _lib.stream_wait(None, side)
+        _lib.tape_release()
         flat.attach_grads()
         if m._grad_hook is not None:
-            m._grad_hook("end")
+            _lib.host_call(lambda: m._grad_hook("end"))
         self.levels = []
         self.probs, self.logits = [], []
         self.done = True
@@ -247,11 +259,12 @@ class _EngineModel(nn.Module):
             self._param_epoch += 1       # running statistics move
         fold = self._fold() if (not self.training and not record) else None
         self._flat.wt_stale = True          # weights may have been updated since the last call
-        x_nhwc = Act(ops.nchw_to_nhwc(x.contiguous().float()), needs_grad=False)
+        x = x.contiguous().float()
+        x_nhwc = None                       # built where a pass needs it (the batched passes build their own stack)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
             rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync(), fold=fold)
-            feats = self._backbone(rec, x_nhwc)
+            feats = self._backbone(rec, Act(ops.nchw_to_nhwc(x), needs_grad=False))
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
             run.levels.append(lv)
@@ -288,7 +301,13 @@ class _EngineModel(nn.Module):
                 if shared is None:
                     rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels, prec=prec,
                                    sync=self._bn_sync())
-                    xx = Act(x_nhwc.data.repeat(n_levels, 1, 1, 1), needs_grad=False)
+                    # the image batch stacked L times (library copy kernels: no ATen launch on the path, so a launch
+                    # tape of the step is complete)
+                    stack = torch.empty((n_levels * Bn, x.shape[2], x.shape[3], x.shape[1]), dtype=torch.float32,
+                                        device=x.device)
+                    for rep in range(n_levels):
+                        ops.nchw_to_nhwc(x, out=stack[rep * Bn:(rep + 1) * Bn])
+                    xx = Act(stack, needs_grad=False)
                     shared, shared_rec = self._backbone(rec, xx), rec
                     run.batched_feats = shared
                 feats, rec = Act(shared.data[L * Bn:(L + 1) * Bn]), shared_rec
@@ -301,6 +320,8 @@ class _EngineModel(nn.Module):
                     xin = Act(ops.concat_image_logits(x, run.logits[L - 1]), needs_grad=record)
                     feats = self._backbone(rec, xin, first=self.cond_stems[L - 1])
                 else:
+                    if x_nhwc is None:
+                        x_nhwc = Act(ops.nchw_to_nhwc(x), needs_grad=False)
                     feats = self._backbone(rec, x_nhwc)
                 if (dedup or (not self.training and not record)) and not concat:
                     shared, shared_rec = feats, rec
@@ -359,6 +380,14 @@ class _EngineModel(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._param_epoch += 1
         return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        """a train <-> eval switch also invalidates the folded inference weights: whatever ran in train mode (an eager
+        step, a hipGraph / launch-tape replay that moves weights and running statistics through raw pointers, an EMA swap
+        through .data) is then seen by the next eval forward without anyone having to call notify_parameters_changed()"""
+        if hasattr(self, "_param_epoch") and bool(mode) != self.training:
+            self._param_epoch += 1
+        return super().train(mode)
 
     def _bn_sync(self):
         """process group for cross-rank BatchNorm statistics, or None (the default: statistics stay per rank)"""
@@ -494,6 +523,7 @@ class UNet(_EngineModel):
             self.films = nn.ModuleList([FiLM(feat_ch=64, cond_ch=len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
             if self.concat_prev_logits:
+                _check_cond_stem_width([n_channels + self.heads[L - 1].conv.out_channels for L in range(1, len(self.levels))])
                 self.cond_stems = nn.ModuleList([Conv2d(n_channels + self.heads[L - 1].conv.out_channels, 64, 3, padding=1)
                                                  for L in range(1, len(self.levels))])
         self._init_engine()
@@ -752,6 +782,7 @@ class HighResolutionNet(_EngineModel):
             self.films = nn.ModuleList([FiLM(feat_ch=last, cond_ch=len(self.levels[L - 1]))
                                         for L in range(1, len(self.levels))])
             if self.concat_prev_logits:
+                _check_cond_stem_width([3 + self.classifiers[L - 1].out_channels for L in range(1, len(self.levels))])
                 self.cond_stems = nn.ModuleList([Conv2d(3 + self.classifiers[L - 1].out_channels, 64, kernel_size=3, stride=2,
                                                         padding=1, bias=False) for L in range(1, len(self.levels))])
         self._init_engine()

@@ -172,9 +172,19 @@ def deterministic() -> bool:
     return _deterministic
 
 
+_tune_generation = 0
+
+
+def tune_generation() -> int:
+    """bumped by every tune() call: recorded launch tapes are keyed by it (the library plans per call, so a replay would
+    follow a new plan anyway, but workspace sizes were fixed when the tape was recorded)"""
+    return _tune_generation
+
+
 def tune(**kv):
     """tile-plan overrides of the library (hrseg_tune; 0 = automatic), e.g. tune(igemm_wtm=2, igemm_kc=1)"""
-    global _deterministic
+    global _deterministic, _tune_generation
+    _tune_generation += 1
     for k, v in kv.items():
         if _lib.hrseg_tune(k.encode(), int(v)) != 0:
             raise RuntimeError(f"hrseg_tune({k}) failed: {last_error()}")
@@ -248,9 +258,98 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Tape:
+    """A recorded sequence of C-ABI calls (plus the stream waits and host callbacks between them) that can be issued
+    again without the Python engine around it: `replay()` is one loop over pre-built ctypes argument tuples.
+
+    What a train step costs on the host is not the ~1,500 launches (3-4 us each inside the library) but the engine that
+    derives them every step: tensor allocations, shape structs, closures, autograd (31 ms of a 52 ms step on a fast
+    host, more than the step on a slow one).  A step whose shapes do not change issues the SAME calls with the SAME
+    pointers as long as its buffers stay where they are, so train.TapedTrainStep records them once -- inside a private
+    torch memory pool whose blocks nobody else can take -- and replays them.  Unlike a captured hipGraph the replay issues
+    real launches on the real streams (main + weight-gradient side stream + the collective's stream), so the two-stream
+    overlap of the eager step is kept, host callbacks (the bucketed gradient all-reduce) run where they ran, and the
+    library still plans every launch itself (tile plans, scratch rings) exactly as in the eager step.
+
+    Entries: (0, cfunc, args, raw stream) | (1, waiting torch stream or None = main, signalling stream or None = main) |
+    (2, callable).  The main stream is whatever stream is current when replay() is called."""
+
+    def __init__(self):
+        self.entries = []
+        self.keep = []          # tensors the recorded side-stream work reads: held until the streams join (see engine.py)
+        self.main = None        # raw handle of the stream that was current while recording
+        self.calls = 0
+
+    def __enter__(self):
+        global _tape
+        if _tape is not None:
+            raise RuntimeError("hrseg_amd: a launch tape is already being recorded")
+        self.main = stream()
+        _tape = self
+        return self
+
+    def __exit__(self, *exc):
+        global _tape
+        _tape = None
+        self.keep = []
+        return False
+
+    def replay(self):
+        cur, rec = stream(), self.main
+        for kind, a, b, c in self.entries:
+            if kind == 0:
+                rc = a(*b, cur if c == rec else c)
+                if rc != 0:
+                    raise RuntimeError(f"{a.__name__} failed ({rc}) in a launch-tape replay: {last_error()}")
+            elif kind == 1:
+                (a if a is not None else torch.cuda.current_stream()).wait_stream(
+                    b if b is not None else torch.cuda.current_stream())
+            else:
+                a()
+
+
+_tape = None
+
+
+def taping() -> bool:
+    """True while a launch tape is being recorded (host readbacks and data-dependent routing must stay out of it)"""
+    return _tape is not None
+
+
+def tape_keep(*tensors):
+    """recording: hold `tensors` until the next tape_release() (what Tensor.record_stream does in the eager step -- whose
+    allocator decides by GPU timing when such a block may be reused, which a replay cannot reproduce)"""
+    _tape.keep.extend(tensors)
+
+
+def tape_release():
+    if _tape is not None:
+        _tape.keep = []
+
+
+def stream_wait(waiter, signaller):
+    """waiter.wait_stream(signaller) for two torch streams (None = the current stream), recorded when a tape is active"""
+    if _tape is not None:
+        _tape.entries.append((1, waiter, signaller, None))
+    (waiter if waiter is not None else torch.cuda.current_stream()).wait_stream(
+        signaller if signaller is not None else torch.cuda.current_stream())
+
+
+def host_call(fn):
+    """run a host callback now; a recording tape runs it again at the same position of every replay (collectives)"""
+    if _tape is not None:
+        _tape.entries.append((2, fn, None, None))
+    fn()
+
+
 def call(name, *args):
     """Invoke an entry point on torch's current stream; raise on failure."""
-    rc = _fn[name](*args, stream())
+    st = stream()
+    f = _fn[name]
+    if _tape is not None:
+        _tape.entries.append((0, f, args, st))
+        _tape.calls += 1
+    rc = f(*args, st)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
 

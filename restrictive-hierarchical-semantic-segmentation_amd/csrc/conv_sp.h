@@ -45,7 +45,8 @@ __device__ __forceinline__ float sp_trunc(float x) { return __uint_as_float(__fl
 // products hi*hi, hi*lo, lo*hi on v_mfma_f32_16x16x32_f16 -- half the matrix work of bf16x3 at 2^-22 operand
 // error.  fp16 has 5 exponent bits, so fp16x2 operands are SCALED by a power of two before the split (weights by a
 // fixed 2^8, gradients by 2^14 / their measured |max|, see sp_pow2_scale) and the accumulators are scaled back in
-// the epilogue; activations are clamped to the fp16 range.  Elements more than 2^19 below the scaled maximum
+// the epilogue; activations are neither scaled nor clamped (exact to 22 bits up to |x| = 65504, Inf / NaN beyond ~1.3e5:
+// include/hrseg.h; ops.py range-checks them in deterministic mode).  Elements more than 2^19 below the scaled maximum
 // lose their low piece to the subnormal range (absolute error <= 2^-25 after scaling): invisible in a dot product.
 constexpr int sp_np(int ns) { return ns == 4 ? 2 : ns; }                       // pieces per operand
 constexpr int sp_products(int ns) { return ns == 1 ? 1 : ns == 3 ? 6 : 3; }

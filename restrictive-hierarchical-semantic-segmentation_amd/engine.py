@@ -188,7 +188,7 @@ class Recorder:
             fn = self.tape.pop()
             if isinstance(fn, str):
                 if hook is not None:
-                    hook(fn)
+                    _lib.host_call(lambda mark=fn: hook(mark))      # (a launch tape re-issues it at this position)
             else:
                 fn()
 
@@ -297,7 +297,7 @@ class Recorder:
             def weight_gradients():
                 side = wgrad_stream(dys[0].device)
                 if side is not None:
-                    side.wait_stream(torch.cuda.current_stream())
+                    _lib.stream_wait(side, None)
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                     if n == 1:
                         ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0])
@@ -305,12 +305,17 @@ class Recorder:
                         ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
                                              prec=self.prec, gmaxs=gmaxs)
                 if side is not None:
-                    if gmax_all is not None:
-                        gmax_all.record_stream(side)
-                    for t in dys:
-                        t.record_stream(side)     # not reused before the side stream is done reading it
-                    for x in xs:
-                        x.data.record_stream(side)
+                    if _lib.taping():
+                        # a recorded step is replayed without the allocator: what the side stream reads stays allocated
+                        # until the streams join at the end of the reverse pass (_Run.backward)
+                        _lib.tape_keep(gmax_all, *dys, *[x.data for x in xs])
+                    else:
+                        if gmax_all is not None:
+                            gmax_all.record_stream(side)
+                        for t in dys:
+                            t.record_stream(side)     # not reused before the side stream is done reading it
+                        for x in xs:
+                            x.data.record_stream(side)
                     self.used_side = True
             if _WGRAD_ORDER != "after":
                 weight_gradients()

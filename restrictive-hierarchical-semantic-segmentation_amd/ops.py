@@ -94,7 +94,8 @@ def _guard_prec(x, prec):
     results far beyond.  In deterministic mode (the verification mode: it may synchronise) the operand is range-checked
     and an out-of-range or non-finite tensor runs the exact-fp32 kernels instead; counted in `range_fallbacks`."""
     global range_fallbacks
-    if not _lib.deterministic() or prec not in _F16_CODES or x.shape[3] % 4 or torch.cuda.is_current_stream_capturing():
+    if not _lib.deterministic() or prec not in _F16_CODES or x.shape[3] % 4 or torch.cuda.is_current_stream_capturing() \
+            or _lib.taping():
         return prec            # (a captured graph cannot read a value back: the guard is an eager-mode check)
     if float(absmax(x)) <= FP16X2_ACT_LIMIT:
         return prec
@@ -266,6 +267,29 @@ def _sync_world(sync):
     return dist.get_world_size(sync)
 
 
+_SYNC_BN_CHECKED = set()
+
+
+def _check_sync_bn_shapes(sync, items, device):
+    """synchronised BatchNorm all-reduces per-chunk partial sums and divides by stat_ranks * npix: every rank must bring the
+    same pixel counts (same per-rank batch: `drop_last=True` in the loader).  Checked ONCE per distinct shape signature (one
+    tiny all-reduce + readback), then cached: a ragged last batch raises here instead of hanging in a mismatched collective
+    or weighting the statistics wrongly."""
+    import torch.distributed as dist
+    sig = (id(sync), tuple(_npix(it["y"]) for it in items))
+    if sig in _SYNC_BN_CHECKED:
+        return
+    v = torch.tensor([len(items)] + [n for n in sig[1]], dtype=torch.int64, device=device)
+    v = torch.cat([v, -v])
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=sync)
+    h = v.tolist()
+    k = len(h) // 2
+    if any(h[i] != -h[k + i] for i in range(k)):
+        raise RuntimeError("hrseg_amd sync_bn: the ranks bring different batch / image sizes to a synchronised BatchNorm "
+                           f"(max over ranks {h[1:k]}, min {[-x for x in h[k + 1:]]}); use equal per-rank batches (drop_last=True)")
+    _SYNC_BN_CHECKED.add(sig)
+
+
 _BN_ACC = {}        # (device index, stream) -> zeroed fp64 arena of the fused-finalize BatchNorm launches
 BN_ACC_ROWS = 16    # csrc/bn_elem.hip BN_ACC_R
 
@@ -304,6 +328,7 @@ def bn_fwd_group(items, training, sync=None):
     ranks = _sync_world(sync) if sync is not None else 1
     pool, pool_off = None, 0
     if sync is not None:
+        _check_sync_bn_shapes(sync, items, items[0]["y"].device)
         total = sum(_nchunks(_npix(it["y"]), it["y"].shape[3]) * 2 * it["y"].shape[3] for it in items)
         pool = torch.empty(total, dtype=torch.float64, device=items[0]["y"].device)
     accs = None
@@ -477,9 +502,10 @@ def relu_bwd(dz, z, out=None):
     return out
 
 
-def nchw_to_nhwc(x):
+def nchw_to_nhwc(x, out=None):
     B, Cn, H, W = x.shape
-    out = empty_nhwc(B, H, W, Cn, x)
+    if out is None:
+        out = empty_nhwc(B, H, W, Cn, x)
     call("hrseg_nchw_to_nhwc", ptr(x), ptr(out), Cn, B, Cn, H, W)
     return out
 

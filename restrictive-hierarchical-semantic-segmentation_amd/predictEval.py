@@ -109,7 +109,11 @@ def prediction_prep(output_logits, target, args, class_tree):
     from .train import split_targets
     if args.model_type == 0:
         logits = output_logits if torch.is_tensor(output_logits) else output_logits[0]
-        onehot, _ = ops.predict_metrics(logits.detach(), target, child=False, mask_pred=True)
+        # the leaf one-hot is NOT masked here: the reference synthesises the parents from the plain arg-max one-hot
+        # (predictEval.py:361-386) and masks every level afterwards (:435-439) -- a parent's target is never -1, so its
+        # prediction keeps the pixels whose LEAF target is -1.  (An all-zero target makes the kernel's mask a no-op.)
+        onehot, _ = ops.predict_metrics(logits.detach(), ops.zeros(logits.shape, torch.float32, logits.device), child=False,
+                                        mask_pred=True)
         index = TreeIndex(class_tree)
         name_to_index = {n: i for i, n in enumerate(index.leaf_names)}
         parent_class, parent_target, _ = get_parent_masks([onehot], [target], class_tree, name_to_index)

@@ -201,13 +201,18 @@ def _append_metrics(vec, accuracy, IoU, dice, precision, recall, clssMetrics, ho
 # ----------------------------------------------------------------------------- loss
 def get_loss(output_logits, targets, lossFuncts, levelLoss, level_weights=None, loss=0.0, lvlLossGrad=[],
              cur_level=None, cur_epoch=None, pretrain_epoch=None, probs_per_level=None, model=None, *, lambda_kl=None,
-             kl_probs=None):
+             kl_probs=None, sync_dice=None):
     """reference train.py:111-152.  With this package's loss objects each level is ONE fused
     CE+Dice launch; ``levelLoss`` accumulates 0-dim device tensors (no .item() sync) that
     behave like the reference's floats under ``+`` and ``/``.
     Extension (keyword-only, default off; the reference's get_loss has no such argument): ``lambda_kl`` adds
     lambda_kl * grouped_conditional_kl per level L >= 1 (the stabiliser of Metrics/losses.py:180-210); ``kl_probs`` are
-    the parent probabilities it is gated with (default: ``probs_per_level``)."""
+    the parent probabilities it is gated with (default: ``probs_per_level``).
+    ``sync_dice``: under data parallelism Dice's divisor is the GLOBAL count of valid items (losses.global_batch_dice: one
+    tiny all-reduce per level).  Default None = only where a gradient is being built (the train step, which every rank
+    runs in lock-step); validation (``test()``, under no_grad, possibly on one rank or on shards of unequal length)
+    never enters a collective and reports the rank-local loss.  ``levelLoss`` always accumulates the unscaled local
+    CE + Dice."""
     total_levels = len(output_logits)
     if pretrain_epoch is not None:
         cur_level_cap = int(min(total_levels - 1, (cur_epoch // pretrain_epoch)))
@@ -222,9 +227,9 @@ def get_loss(output_logits, targets, lossFuncts, levelLoss, level_weights=None, 
             res = losses.fused_ce_dice(output_logits[L], targets[L], level_weight)
             # Dice is 0 with zero gradient when no item is valid == the reference skipping None; under data
             # parallelism its divisor is the global count of valid items (losses.global_batch_dice)
-            level = res[0] + losses.global_batch_dice(res)
-            loss = loss + level
-            levelLoss[L] = levelLoss[L] + level.detach()
+            sync = (torch.is_grad_enabled() and res.requires_grad) if sync_dice is None else bool(sync_dice)
+            loss = loss + res[0] + (losses.global_batch_dice(res) if sync else res[1])
+            levelLoss[L] = levelLoss[L] + (res[0] + res[1]).detach()
         else:
             loss_ce = ce_fn(output_logits[L], targets[L], class_weight=level_weight, logits_input=True)
             loss_dice = dice_fn(output_logits[L], targets[L], class_weight=level_weight, logits_input=True)
@@ -319,7 +324,231 @@ class GraphedTrainStep:
         self.t.copy_(target, non_blocking=True)
         self.optimizer._sync_hyper(self.x.device)
         self.graph.replay()
+        # the replay moved weights and running statistics through raw pointers: neither FusedAdamW.step() nor the model's
+        # forward ran on the host, so the folded inference weights must be told
+        _unwrap(self.model).notify_parameters_changed()
         return self.loss, self.cms
+
+
+class TapedTrainStep:
+    """One train step (the batch body of train_epoch: zero_grad, forward of the L passes, prediction prep + confusion
+    counts, CE + Dice + consistency, backward, gradient exchange, AdamW, metric vectors) recorded ONCE as a launch tape
+    (_lib.Tape: the C-ABI calls, stream waits and host callbacks of the step) and re-issued per batch.
+
+    Why: the eager step spends 31 ms of host time per 52 ms step on a fast host deriving the same ~1,500 launches again
+    (allocations, shape structs, closures, autograd); on a slower host -- or with eight ranks sharing one -- the step is
+    host-bound and no kernel gain shows.  A replay costs the library's own planning + launch time only.  Unlike the hipGraph
+    of GraphedTrainStep the replay issues real launches on the real streams: the weight-gradient side stream overlaps
+    the data-gradient chain exactly as in the eager step (a replayed hipGraph serialises them on this stack: 55.8 vs 51.7
+    ms), and the bucketed all-reduce of a gradient hook runs at its tape positions, so this is also the multi-GPU step.
+
+    The body is the engine-level form of `train_step`: no autograd node, no ATen kernel -- the loss gradient seeds
+    ([1, dice scale, 0] per level) are static tensors, the scalars of the step come back as ONE small vector.  It is
+    recorded inside a private torch memory pool: every buffer of the step keeps its address for the life of this
+    object and nobody else can be handed those blocks; what the side stream reads is held until the streams join (the
+    eager step's record_stream leaves that to allocator timing, which a replay cannot reproduce).  The recording run is
+    a real step (its results are returned like any other).  Same kernels, same arguments, same order as `train_step`:
+    bit-identical to it in deterministic mode (tests/test_tape_gpu.py).
+
+    Needs the package's fused loss objects (losses.CrossEntropyLoss + losses.SoftDiceLoss per level) and fixed shapes;
+    `for_batch` of a TapedStepCache re-records per shape."""
+
+    def __init__(self, model, optimizer, lossFuncts, args, class_tree, data, target, epoch_num=1):
+        from . import _lib
+        self._lib = _lib
+        self.model, self.optimizer, self.args = model, optimizer, args
+        m = _unwrap(model)
+        for ce_fn, dice_fn in lossFuncts:
+            if not (isinstance(ce_fn, losses.CrossEntropyLoss) and isinstance(dice_fn, losses.SoftDiceLoss)):
+                raise TypeError("TapedTrainStep needs losses.CrossEntropyLoss / losses.SoftDiceLoss per level")
+        if m._bn_sync() is not None:
+            raise NotImplementedError("TapedTrainStep: synchronised BatchNorm issues collectives inside the layers; use the "
+                                      "eager step (HRSEG_TAPE=0)")
+        self.hier = args.model_type == 1
+        self.n_levels = len(args.num_classes) if self.hier else 1
+        cap = self.n_levels - 1
+        if getattr(args, "level0_pretrain_epochs", None) is not None:
+            cap = int(min(self.n_levels - 1, epoch_num // args.level0_pretrain_epochs))
+        self.level_cap = cap
+        dev = data.device
+        self.x = data.detach().clone().float().contiguous()
+        self.t = target.detach().clone().float().contiguous()
+        self.t_levels = [torch.empty_like(v) for v in split_targets(self.t, args)] if self.hier else [self.t]
+        weights = args.level_weights
+        self.w = [losses._weights(weights[L] if self.hier else weights[0], dev) for L in range(self.n_levels)]
+        # d loss / d (ce, dice, n_valid) per level; the Dice entry carries the data-parallel divisor correction
+        self.seed = [torch.tensor([1.0, 1.0, 0.0], dtype=torch.float32, device=dev) for _ in range(self.n_levels)]
+        self._n_all = torch.zeros(self.n_levels, dtype=torch.float32, device=dev)
+        self.groups = []
+        if self.hier and hasattr(m, "levels") and hasattr(m, "parent_of"):
+            for L in range(1, len(m.levels)):
+                g = losses._level_groups(m.levels, m.parent_of, L)
+                self.groups.append(([p for p, _ in g], [len(ch) for _, ch in g]) if g else None)
+        # everything that outlives the step exists BEFORE the pool is entered (the pool owns only the step's own buffers):
+        # flat parameter / gradient buffers, optimizer moments and scalars, the library's scratch buffer
+        m.flatten_parameters(dev)
+        optimizer._moments()
+        optimizer._sync_hyper(dev)
+        _lib.ensure_scratch(dev)
+        self.pool = torch.cuda.MemPool()
+        self.tape = _lib.Tape()
+        self.replays = 0
+        self._load(data, target, copy=False)
+        with torch.cuda.use_mem_pool(self.pool, device=dev), torch.no_grad():
+            with self.tape:
+                self.out = self._body()
+        _unwrap(self.model).notify_parameters_changed()
+
+    # ------------------------------------------------------------------ the recorded body
+    def _dice_sync(self, outs):
+        """host callback at its tape position: Dice's divisor under data parallelism (losses.global_batch_dice) as the
+        gradient seed and the value scale of every level -- ONE all-reduce of n_levels floats"""
+        import torch.distributed as dist
+        world = float(dist.get_world_size())
+        n_local = torch.stack([o[2] for o in outs])
+        self._n_all.copy_(n_local)
+        dist.all_reduce(self._n_all, op=dist.ReduceOp.SUM)
+        scale = torch.where(self._n_all > 0, n_local * world / self._n_all.clamp(min=1.0), torch.zeros_like(n_local))
+        for L, sd in enumerate(self.seed):
+            sd[1:2].copy_(scale[L:L + 1])
+
+    def _body(self):
+        import torch.distributed as dist
+        _lib = self._lib
+        m = _unwrap(self.model)
+        flat = m.flatten_parameters(self.x.device)
+        ops.fill(flat.grad, 0.0)
+        flat.grads_fresh = True
+        for p in flat.params:
+            p.grad = None
+        run = m._run(self.x, True)
+        logits = run.logits
+        onehots, cms, outs, coefs = [], [], [], []
+        for L, (z, t) in enumerate(zip(logits, self.t_levels)):
+            oh, cm = ops.predict_metrics(z, t, child=(L > 0), mask_pred=True)
+            onehots.append(oh)
+            cms.append(cm)
+        for L, (z, t) in enumerate(zip(logits, self.t_levels)):
+            if L > self.level_cap:
+                outs.append(None)
+                coefs.append(None)
+                continue
+            o, c = ops.loss_fwd(z, t, self.w[L])
+            outs.append(o)
+            coefs.append(c)
+        cons = []
+        for L, g in enumerate(self.groups, start=1):
+            if g is not None:
+                cons.append((ops.consistency_sums(onehots[L], onehots[L - 1], g[0], g[1]), len(g[0]),
+                             1.0 / (onehots[L].shape[0] * onehots[L].shape[2] * onehots[L].shape[3])))
+        live = [o for o in outs if o is not None]
+        self.synced = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.synced:
+            if len(live) != self.n_levels:
+                raise NotImplementedError("TapedTrainStep: level0_pretrain_epochs together with data parallelism")
+            _lib.host_call(lambda: self._dice_sync(live))
+        dz = [ops.loss_bwd(z, t, coefs[L], self.seed[L]) if outs[L] is not None else None
+              for L, (z, t) in enumerate(zip(logits, self.t_levels))]
+        n_probs = len(run.probs)
+        run.backward([None] * n_probs, dz)
+        self.optimizer.step()
+        vec = ops.metric_vectors(cms, [L > 0 for L in range(len(cms))])
+        return dict(outs=outs, cons=cons, cms=cms, vec=vec)
+
+    # ------------------------------------------------------------------ per batch
+    def _load(self, data, target, copy=True):
+        if copy:
+            self.x.copy_(data, non_blocking=True)
+            self.t.copy_(target, non_blocking=True)
+        for dst, src in zip(self.t_levels, split_targets(self.t, self.args)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+
+    def __call__(self, data, target):
+        """-> (packed scalars of the step [device], per-level confusion matrices): `unpack` reads them on the host"""
+        self._load(data, target)
+        self.optimizer._sync_hyper(self.x.device)
+        self.optimizer._step += 1
+        self.tape.replay()
+        self.replays += 1
+        _unwrap(self.model).notify_parameters_changed()
+        return self.result()
+
+    def result(self):
+        """(packed scalars, confusion matrices) of the latest run of the step -- after construction: of the recording run,
+        which was a real train step on the batch the object was built with"""
+        return self._packed(), self.out["cms"]
+
+    def _packed(self):
+        o = self.out
+        parts = [v.double() for v in o["outs"] if v is not None] + [c[0].reshape(-1) for c in o["cons"]] + \
+                [torch.stack([sd[1] for sd in self.seed]).double(), o["vec"].reshape(-1).double()]
+        return torch.cat(parts)
+
+    def unpack(self, host):
+        """host list of `_packed()` -> (loss, per-level CE+Dice list, metric rows [5][sum C]) with the arithmetic of
+        get_loss (fp32 adds in level order, Dice scaled by the data-parallel seed, consistency = mean over groups)"""
+        o = self.out
+        i, loss, levels, raw = 0, np.float32(0.0), [], []
+        for v in o["outs"]:
+            raw.append(None if v is None else (np.float32(host[i]), np.float32(host[i + 1])))
+            i += 0 if v is None else 3
+        i_cons = i
+        i += sum(ngroups for _, ngroups, _ in o["cons"])
+        seeds = host[i:i + self.n_levels]
+        i += self.n_levels
+        for L, cd in enumerate(raw):
+            if cd is None:
+                levels.append(0.0)
+                continue
+            loss = np.float32(np.float32(loss + cd[0]) + np.float32(cd[1] * np.float32(seeds[L])))
+            levels.append(float(np.float32(cd[0] + cd[1])))
+        if o["cons"]:
+            total, count, j = np.float32(0.0), 0, i_cons
+            for sums, ngroups, scale in o["cons"]:
+                part = np.float32(np.float64(sum(host[j:j + ngroups])) * scale)
+                j += ngroups
+                total = np.float32(total + part)
+                count += ngroups
+            loss = np.float32(loss + np.float32(total / np.float32(count)))
+        vec = host[i:]
+        n = len(vec) // len(METRIC_NAMES)
+        return float(loss), levels, [vec[k * n:(k + 1) * n] for k in range(len(METRIC_NAMES))]
+
+
+TAPE_CACHE_MAX = 3      # recorded steps kept per model (one per batch shape; each owns its activations' memory)
+
+
+def taped_step_for(model, optimizer, lossFuncts, args, class_tree, data, target, epoch_num=1):
+    """the launch tape of this (model configuration, batch shape), recorded on first use -> (TapedTrainStep, fresh):
+    `fresh` = the object was just built, i.e. the step on (data, target) has ALREADY run (read step.result()).
+    None when tapes are off (HRSEG_TAPE=0), the losses are not the fused pair, or the cache is full."""
+    import os
+    from . import _lib
+    if os.environ.get("HRSEG_TAPE", "1") == "0" or not data.is_cuda:
+        return None, False
+    if not all(isinstance(c, losses.CrossEntropyLoss) and isinstance(d, losses.SoftDiceLoss) for c, d in lossFuncts):
+        return None, False
+    m = _unwrap(model)
+    if not hasattr(m, "_bn_sync") or m._bn_sync() is not None:
+        return None, False
+    cap = None
+    if getattr(args, "level0_pretrain_epochs", None) is not None:
+        cap = int(epoch_num // args.level0_pretrain_epochs)
+    import torch.distributed as dist
+    key = (tuple(data.shape), tuple(target.shape), id(optimizer), cap, getattr(m, "conv_dtype", None),
+           bool(getattr(m, "dedup_passes", False)), bool(getattr(m, "sequential_passes", False)),
+           bool(getattr(m, "sync_bn", False)), _lib.deterministic(), _lib.tune_generation(), id(m._grad_hook),
+           dist.is_available() and dist.is_initialized() and dist.get_world_size(), m.training,
+           tuple(tuple(float(v) for v in w) for w in args.level_weights))
+    cache = m.__dict__.setdefault("_hr_tapes", {})
+    step = cache.get(key)
+    if step is not None:
+        return step, False
+    if len(cache) >= TAPE_CACHE_MAX:
+        return None, False
+    step = cache[key] = TapedTrainStep(model, optimizer, lossFuncts, args, class_tree, data, target, epoch_num)
+    return step, True
 
 
 def _unwrap(model):
@@ -341,16 +570,40 @@ def train_epoch(model, device, train_loader, optimizer, epoch, lossFuncts, args,
     n_batches = len(train_loader)
     for batch_idx, (data, target) in enumerate(train_loader):
         data, target = data.to(device), target.to(device)
-        loss, cms = train_step(model, optimizer, data, target, lossFuncts, args, class_tree, levelLoss, epoch_num)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            from .parallel import all_reduce_confusion
-            cms = all_reduce_confusion(cms)          # metrics of the global batch, as on the reference's GPU 0
-        vec = _metric_vectors(cms)
-        # the only device->host copy of the step: loss + every per-class metric
-        host = torch.cat([loss.reshape(1)] + [vec[k] for k in METRIC_NAMES]).tolist()
-        n = len(host[1:]) // len(METRIC_NAMES)
-        _append_metrics(vec, accuracy, IoU, dice, precision, recall, clssMetrics,
-                        host=[host[1 + i * n:1 + (i + 1) * n] for i in range(len(METRIC_NAMES))])
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size() > 1
+        # default: the step is a recorded launch tape (TapedTrainStep), re-recorded per batch shape; HRSEG_TAPE=0 or
+        # foreign loss objects: the eager step
+        taped, fresh = taped_step_for(model, optimizer, lossFuncts, args, class_tree, data, target, epoch_num)
+        if taped is not None:
+            packed, cms = taped.result() if fresh else taped(data, target)
+            if multi:
+                from .parallel import all_reduce_confusion
+                extra = _metric_vectors(all_reduce_confusion(cms))      # metrics of the global batch (reference: GPU 0)
+                packed = torch.cat([packed] + [extra[k].double() for k in METRIC_NAMES])
+            host = packed.tolist()                   # the only device->host copy of the step
+            n_extra = len(METRIC_NAMES) * sum(args.num_classes) if multi else 0
+            loss_value, levels, per = taped.unpack(host[:len(host) - n_extra])
+            if multi:
+                tail, n = host[len(host) - n_extra:], sum(args.num_classes)
+                per = [tail[i * n:(i + 1) * n] for i in range(len(METRIC_NAMES))]
+            if len(levelLoss) != len(levels):
+                levelLoss[:] = [0.0] * len(levels)
+            for L, v in enumerate(levels):
+                levelLoss[L] = levelLoss[L] + v
+            _append_metrics(None, accuracy, IoU, dice, precision, recall, clssMetrics, host=per)
+            host = [loss_value]
+        else:
+            loss, cms = train_step(model, optimizer, data, target, lossFuncts, args, class_tree, levelLoss, epoch_num)
+            if multi:
+                from .parallel import all_reduce_confusion
+                cms = all_reduce_confusion(cms)          # metrics of the global batch, as on the reference's GPU 0
+            vec = _metric_vectors(cms)
+            # the only device->host copy of the step: loss + every per-class metric
+            host = torch.cat([loss.reshape(1)] + [vec[k] for k in METRIC_NAMES]).tolist()
+            n = len(host[1:]) // len(METRIC_NAMES)
+            _append_metrics(vec, accuracy, IoU, dice, precision, recall, clssMetrics,
+                            host=[host[1 + i * n:1 + (i + 1) * n] for i in range(len(METRIC_NAMES))])
         loss_accumulator.append(host[0])
         last = batch_idx + 1 == n_batches
         print("\rTrain Epoch: {} [{}/{} ({:.1f}%)]\t{}: {:.6f}\tTime: {:.6f}".format(

@@ -156,6 +156,38 @@ def test_predict_loop_matches_the_oracle(kind, hier, tmp_path):
     assert len(rows) == 2 + sum(nc_full) and rows[2][:2] == ["Class", "0"]
 
 
+def test_flat_prediction_prep_keeps_parent_predictions_under_ignored_leaf_pixels():
+    """flat models (predictEval.py:361-386, :435-439): parents are the union of the UNMASKED leaf one-hot, the -1 mask is
+    applied per level afterwards -- a parent target is never -1, so its prediction survives where a leaf target is -1"""
+    from oracle import metrics as OM
+    from oracle import predict_eval as OPE
+    from hrseg_amd import predictEval as PE
+    tree = load_tree("class_tree_tl.json")
+    ch = OPE.children_map(tree)
+    leaves = [n for n in OPE.bfs_order(tree) if not ch[n]]
+    parents = [n for n in OPE.bfs_order(tree) if ch[n]]
+    g = np.random.Generator(np.random.PCG64(77))
+    z = g.standard_normal((2, len(leaves), 24, 24)).astype(np.float32)
+    lab = g.integers(0, len(leaves), size=(2, 24, 24))
+    t = np.stack([(lab == c) for c in range(len(leaves))], 1).astype(np.float32)
+    t[:, :, 5:12, 3:20] = -1.0                      # a block of ignored leaf pixels
+    t[0, 4, :, :6] = -1.0                           # and one leaf ignored on its own
+    args = argparse.Namespace(model_type=0, num_classes=[len(leaves)])
+    got_cls, got_tgt = PE.prediction_prep(torch.from_numpy(z).cuda(), torch.from_numpy(t).cuda(), args, tree)
+    oh = OM.one_hot_predictions(z)
+    px, py, _ = OPE.get_parent_masks(oh, t, tree, {n: i for i, n in enumerate(leaves)})
+    preds = OPE.combine_levels(oh, px, tree, leaves, parents)
+    targets = OPE.combine_levels(t, py, tree, leaves, parents)
+    assert len(got_cls) == len(preds)
+    differs_from_masked_leaves = False
+    for L, (p, tt) in enumerate(zip(preds, targets)):
+        want = np.where(tt == -1, 0.0, p).astype(np.float32)
+        assert np.array_equal(got_cls[L].cpu().numpy(), want), L
+        assert np.array_equal(got_tgt[L].cpu().numpy(), np.where(tt == -1, 0.0, tt).astype(np.float32)), L
+        differs_from_masked_leaves |= bool((want[:, :, 5:12, 3:20] > 0).any())
+    assert differs_from_masked_leaves          # (the case really has parent predictions under ignored leaf pixels)
+
+
 @pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64", "hrnet_flat_tl_64"])
 def test_inference_with_folded_batchnorm_matches_the_goldens_and_the_unfolded_path(name):
     """eval-mode forward with BatchNorm folded into the convolution weights and residual + ReLU in the convolution epilogue

@@ -1,0 +1,179 @@
+"""The recorded launch tape of the train step (train.TapedTrainStep, the default way train_epoch and bench.py issue a step)
+against the eager step it was recorded from: same kernels, same arguments, same order -- in deterministic mode the same BITS
+(losses, confusion counts, weights, BN buffers, optimizer moments) over several steps on changing batches; in the default mode
+the same values to atomic-order noise.  Also: the recorded body contains no ATen launch (a launch the tape would silently
+drop), folded inference weights follow a replay, and train_epoch gives the same epoch through either path."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import CASES, build_model, level_weights_for, load_golden, load_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, lr=1e-3):
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    kind, hier, tree_file, size, batch = CASES[name]
+    g = load_golden(name)
+    tree = load_tree(tree_file)
+    nc = [int(v) for v in g["num_classes"]]
+    args = argparse.Namespace(model_type=1 if hier else 0, model_select=0 if kind == "unet" else 1, num_classes=nc,
+                              level_weights=level_weights_for(tree_file, hier), level0_pretrain_epochs=None, batch_size=batch)
+    model = build_model(PM, kind, hier, tree, size).cuda()
+    model.train()
+    opt = PT.FusedAdamW(model, lr=[lr])
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=n)] for n in nc]
+    return model, opt, fns, args, tree, g
+
+
+def _batches(g, n):
+    """n different batches of the golden's shape (the golden batch, then seeded perturbations of it)"""
+    x0, t0 = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["target"]).cuda()
+    out = [(x0, t0)]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for i in range(1, n):
+        out.append((x0 + 0.1 * torch.randn(x0.shape, generator=gen, device="cuda"), t0.roll(i, dims=-1).contiguous()))
+    return out
+
+
+@pytest.mark.parametrize("name", ["hrnet_hier_tl_64", "unet_hier_tl_62", "hrnet_flat_tl_64"])
+def test_tape_replay_is_bit_identical_to_the_eager_step_in_deterministic_mode(name):
+    from hrseg_amd import _lib, train as PT
+    _lib.set_deterministic(True)
+    try:
+        batches = None
+        results = {}
+        for mode in ("eager", "tape"):
+            model, opt, fns, args, tree, g = _setup(name)
+            batches = batches or _batches(g, 4)
+            losses, cms_all, ll = [], [], []
+            taped = None
+            for i, (x, t) in enumerate(batches):
+                if mode == "eager":
+                    loss, cms = PT.train_step(model, opt, x, t, fns, args, tree, ll)
+                    losses.append(float(loss))
+                else:
+                    if taped is None:
+                        taped = PT.TapedTrainStep(model, opt, fns, args, tree, x, t)
+                        packed, cms = taped.result()
+                    else:
+                        packed, cms = taped(x, t)
+                    losses.append(taped.unpack(packed.tolist())[0])
+                cms_all.append([c.cpu().clone() for c in cms])
+            torch.cuda.synchronize()
+            if mode == "tape":
+                assert taped.replays == len(batches) - 1 and taped.tape.calls > 50
+            results[mode] = (losses, cms_all, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                             opt._m.cpu().clone(), opt._v.cpu().clone(), int(opt._state[0].item()))
+        (le, ce, se, me, ve, ne), (lt, ct, st, mt, vt, nt) = results["eager"], results["tape"]
+        assert ne == nt == len(batches)
+        assert le == lt, (le, lt)                       # the host-side arithmetic of unpack() is get_loss's, bit for bit
+        for a, b in zip(ce, ct):
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
+        for k in se:
+            assert torch.equal(se[k], st[k]), k
+        assert torch.equal(me, mt) and torch.equal(ve, vt)
+    finally:
+        _lib.set_deterministic(False)
+
+
+def test_tape_replay_tracks_the_eager_step_in_the_default_mode():
+    """default (atomics on): three steps through either path agree to the run-to-run noise of the eager step itself"""
+    from hrseg_amd import train as PT
+    res = {}
+    for mode in ("eager", "eager2", "tape"):
+        model, opt, fns, args, tree, g = _setup("hrnet_hier_tl_64", lr=1e-4)
+        bs = _batches(g, 3)
+        losses, taped, ll = [], None, []
+        for x, t in bs:
+            if mode != "tape":
+                losses.append(float(PT.train_step(model, opt, x, t, fns, args, tree, ll)[0]))
+            elif taped is None:
+                taped = PT.TapedTrainStep(model, opt, fns, args, tree, x, t)
+                losses.append(taped.unpack(taped.result()[0].tolist())[0])
+            else:
+                losses.append(taped.unpack(taped(x, t)[0].tolist())[0])
+        res[mode] = losses
+    noise = max(abs(a - b) for a, b in zip(res["eager"], res["eager2"]))
+    for a, b in zip(res["eager"], res["tape"]):
+        assert abs(a - b) <= max(5e-4 * abs(a), 4 * noise), (res, noise)
+
+
+def test_recorded_body_launches_no_aten_kernel():
+    """a kernel torch launches inside the recorded body would be missing from every replay: the body must consist of
+    C-ABI calls only.  One more pass of the body under the profiler: every device activity is one of the library's kernels."""
+    from torch.profiler import ProfilerActivity, profile
+    from hrseg_amd import train as PT
+    model, opt, fns, args, tree, g = _setup("hrnet_hier_tl_64")
+    x, t = _batches(g, 1)[0]
+    taped = PT.TapedTrainStep(model, opt, fns, args, tree, x, t)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with torch.no_grad():
+            taped._body()
+        torch.cuda.synchronize()
+    names = [ev.name for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA]
+    assert len(names) > 100
+    foreign = [n for n in names if "at::" in n or "Memcpy" in n or "Memset" in n or "elementwise_kernel" in n]
+    assert not foreign, sorted(set(foreign))
+
+
+@pytest.mark.parametrize("kind", ["tape", "graph"])
+def test_folded_inference_weights_follow_replayed_steps(kind):
+    """eval, replay k steps (no host-side optimizer.step / model forward runs), eval -- the second eval must see
+    the new weights and running statistics: compared with the unfolded inference path (fold_bn = False)"""
+    from hrseg_amd import train as PT
+    model, opt, fns, args, tree, g = _setup("unet_hier_tl_62", lr=1e-2)
+    x, t = _batches(g, 1)[0]
+
+    def eval_logits(fold):
+        model.eval()
+        model.fold_bn = fold
+        with torch.no_grad():
+            _, z = PT._model_call(model, x, args, tree)
+        model.fold_bn = True
+        model.train()
+        return [v.clone() for v in z]
+
+    before = eval_logits(True)
+    step = PT.TapedTrainStep(model, opt, fns, args, tree, x, t) if kind == "tape" else \
+        PT.GraphedTrainStep(model, opt, fns, args, tree, x, t, warmup=1)
+    for _ in range(3):
+        step(x, t)
+    folded, plain = eval_logits(True), eval_logits(False)
+    for a, b, c in zip(folded, plain, before):
+        assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max())
+        assert float((a - c).abs().max()) > 1e-2 * float(c.abs().max())        # the steps did move the outputs
+
+
+def test_train_epoch_is_the_same_epoch_with_and_without_the_tape(monkeypatch):
+    from hrseg_amd import _lib, train as PT
+    from hrseg_amd.Metrics import performance_metrics as PP
+    _lib.set_deterministic(True)
+    try:
+        out = {}
+        for tape in ("1", "0"):
+            monkeypatch.setenv("HRSEG_TAPE", tape)
+            model, opt, fns, args, tree, g = _setup("unet_hier_tl_62")
+            loader = PT.synthetic_loader(tree, 6, 62, 2, hierarchical=True, seed=3)
+            mets = [PP.Accuracy(), PP.Jaccardindex(), PP.DiceScore(), PP.Precision(), PP.Recall()]
+            r = PT.train_epoch(model, torch.device("cuda"), loader, opt, 1, fns, args, tree, None, *mets, 1)
+            out[tape] = (r, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                         len(getattr(model, "_hr_tapes", {})))
+        (ra, sa, na), (rb, sb, nb) = out["1"], out["0"]
+        assert na == 1 and nb == 0
+        assert ra[0] == rb[0] and ra[2:7] == rb[2:7]
+        assert np.allclose(ra[7], rb[7], rtol=1e-6, atol=0)
+        for ma, mb in zip(ra[1], rb[1]):
+            assert ma == mb
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    finally:
+        _lib.set_deterministic(False)
