@@ -102,3 +102,80 @@ class conv_mode:
             assert c["ws"] + c["ws_group"] > 0 and c["wgrad9"] > 0, c
             if kind == "hrnet":
                 assert c["ws_group"] > 0 and c["sp_im2col"] + c["sp_group"] > 0, c
+
+
+# ---- opt-in extension `concat_prev_logits`: oracle side of tests/test_models_gpu.py::test_concat_prev_logits_...
+def concat_model(models_mod, kind, size, tree):
+    if kind == "unet":
+        m = models_mod.UNet(size=size, n_channels=3, hierarchy=tree, model_type=1, concat_prev_logits=True)
+    else:
+        m = models_mod.HighResolutionNet(hrnet_w48_config(), hierarchy=tree, model_type=1, concat_prev_logits=True)
+    return synth.fill_state_dict(m)
+
+
+def concat_inputs(tree, size):
+    import torch
+    xn, tn = synth.synthetic_batch(tree, 2, size, seed=31, hierarchical=True, blob=4)
+    return torch.from_numpy(xn), torch.from_numpy(tn)
+
+
+def concat_oracle_results(kind, size):
+    """the CPU oracle twin of the logit-concatenated model: train-mode logits and loss (fp32), the gradients of cond_stems
+    in fp32 and fp64, level 0's head gradient in fp64 and with level 1's input DETACHED from level 0's logits, eval logits"""
+    import torch
+    from oracle import losses as OL
+    from oracle import models as OM
+    tree = load_tree("class_tree_tl.json")
+    weights = level_weights_for("class_tree_tl.json", True)
+    x, target = concat_inputs(tree, size)
+    head0 = "heads.0.conv.weight" if kind == "unet" else "classifiers.0.weight"
+
+    def run(model, xin, dtype):
+        model.train()
+        _, z = model(xin, type=1) if kind == "unet" else model(xin)
+        loss = 0.0
+        for L, a in enumerate(z):
+            t = target[:, 4 * L:4 * L + 4].to(dtype)
+            loss = loss + OL.cross_entropy_loss(a, t, logits_input=True, class_weight=weights[L]) + \
+                OL.soft_dice_loss(a, t, logits_input=True, class_weight=weights[L])
+        loss.backward()
+        return z, loss
+
+    out = {}
+    om = concat_model(OM, kind, size, tree)
+    out["param_names"] = np.array([n for n, _ in om.named_parameters()])
+    z, loss = run(om, x, torch.float32)
+    for L, a in enumerate(z):
+        out[f"train_logits{L}"] = a.detach().numpy().copy()
+    out["loss"] = np.float32(loss.item())
+    for n, p in om.named_parameters():
+        if n.startswith("cond_stems."):
+            out["g32::" + n] = p.grad.numpy().copy()
+    om.eval()
+    with torch.no_grad():
+        _, ze = om(x, type=1) if kind == "unet" else om(x)
+    for L, a in enumerate(ze):
+        out[f"eval_logits{L}"] = a.numpy().copy()
+    o64 = concat_model(OM, kind, size, tree).double()
+    run(o64, x.double(), torch.float64)
+    for n, p in o64.named_parameters():
+        if n.startswith("cond_stems.") or n == head0:
+            out["g64::" + n] = p.grad.numpy().copy()
+
+    class _Detach(torch.nn.Module):
+        def __init__(self, conv):
+            super().__init__()
+            self.conv = conv
+
+        def forward(self, xin):
+            return self.conv(torch.cat([xin[:, :3], xin[:, 3:].detach()], dim=1))
+    om2 = concat_model(OM, kind, size, tree)
+    om2.cond_stems = torch.nn.ModuleList([_Detach(c) for c in om2.cond_stems])
+    run(om2, x, torch.float32)
+    out["gdet::" + head0] = dict(om2.named_parameters())[head0].grad.numpy().copy()
+    return out
+
+
+def load_concat_fixture(kind, size):
+    path = os.path.join(GOLDEN, f"concat_oracle_{kind}_{size}.npz")
+    return np.load(path, allow_pickle=False) if os.path.exists(path) else None

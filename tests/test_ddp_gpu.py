@@ -186,12 +186,7 @@ def _syncbn_worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
-# (opt-in feature: the UNet case always runs, the 20 s HRNet case with HRSEG_SLOW_TESTS=1)
-@pytest.mark.parametrize("name", [
-    "unet_hier_tl_62",
-    pytest.param("hrnet_hier_tl_64", marks=pytest.mark.skipif(not os.environ.get("HRSEG_SLOW_TESTS"),
-                                                              reason="slow: set HRSEG_SLOW_TESTS=1")),
-])
+@pytest.mark.parametrize("name", ["unet_hier_tl_62", "hrnet_hier_tl_64"])
 def test_two_rank_sync_bn_equals_the_gathered_batch(name, tmp_path):
     """model.sync_bn: BatchNorm statistics (forward) and batch means (backward) over both ranks' shards.  With the global
     Dice divisor the two-rank step then IS the single-process step on the gathered batch: mean of the rank losses, the

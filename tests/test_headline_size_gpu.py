@@ -1,0 +1,185 @@
+"""The headline geometry against the REFERENCE (not properties): 620 x 620, class_tree_tl.json, hierarchical, batch 2, for
+HRNet-W48 (BASELINE configs[2]) and UNet (configs[1]), against tests/golden/*_620_b2.npz -- written by
+tests/golden/gen_golden_620.py from the imported reference, in fp32 and in fp64 -- under the DEFAULT routing: the tile plans
+that exist only at this size (canvas tiling of the 20 / 39-pixel branches, the wide im2col and wide weight-gradient bodies,
+four-branch wave-specialised groups with the real block partition, nine-tap weight gradients on 155-pixel images) meet the
+reference's numbers here, and the test asserts through hrseg_launch_count that those kernels are the ones that ran.
+Plus BASELINE configs[0] exactly as written (flat UNet, batch 2, 128 x 128) against the CPU oracle."""
+import argparse
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_model, level_weights_for, load_golden, load_tree, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+FAMILIES = ("ws", "ws_group", "ws_canvas", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "sp_wide", "f32", "f32_group",
+            "wgrad9", "wgrad_sp", "wgrad_sp_group", "wgrad_sp_wide", "wgrad_f32", "wgrad_f32_group", "small_cin")
+
+
+def _crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def _projection_vector(name, numel):
+    from hrseg_amd.utils import synth
+    return synth._rng("proj::" + name).integers(0, 2, size=numel).astype(np.float64) * 2.0 - 1.0
+
+
+@pytest.mark.parametrize("name", ["hrnet_hier_tl_620_b2", "unet_hier_tl_620_b2"])
+def test_headline_size_matches_the_reference_fixture(name):
+    from hrseg_amd import _lib, ops
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    from hrseg_amd.utils import synth
+    kind = name.split("_")[0]
+    g = load_golden(name)
+    tree = load_tree("class_tree_tl.json")
+    size, batch, seed, lat = int(g["size"]), int(g["batch"]), int(g["seed"]), int(g["lattice"])
+    x_np, t_np = synth.synthetic_batch(tree, batch, size, seed=seed, hierarchical=True)
+    assert _crc(x_np) == int(g["x_crc32"]) and _crc(t_np) == int(g["target_crc32"])     # the generator's inputs, rebuilt
+    num_classes = [int(v) for v in g["num_classes"]]
+    weights = level_weights_for("class_tree_tl.json", True)
+    args = argparse.Namespace(model_type=1, model_select=0 if kind == "unet" else 1, num_classes=num_classes,
+                              level_weights=weights, level0_pretrain_epochs=None, batch_size=batch)
+    model = build_model(PM, kind, True, tree, size).cuda()
+    assert [n for n, _ in model.named_parameters()] == list(g["grad_names"])
+    x, target = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
+    sl = (slice(None), slice(None), slice(0, None, lat), slice(0, None, lat))
+
+    model.eval()
+    with torch.no_grad():
+        _, logits = PT._model_call(model, x, args, tree)
+    for L, z in enumerate(logits):
+        assert rel_err(z[sl].cpu().numpy(), g[f"eval_logits{L}"]) < TOL, f"eval logits {L}"
+
+    model.train()
+    _lib.launch_count(None, reset=True)
+    for f in FAMILIES:
+        _lib.launch_count(f, reset=True)
+    probs, logits = PT._model_call(model, x, args, tree)
+    targets = PT.split_targets(target, args)
+    loss, onehots = 0.0, []
+    for L, (z, t) in enumerate(zip(logits, targets)):
+        assert rel_err(z.detach()[sl].cpu().numpy(), g[f"logits{L}"]) < TOL, f"logits {L}"
+        assert rel_err(probs[L].detach()[sl].cpu().numpy(), g[f"probs{L}"]) < TOL, f"probs {L}"
+        res = PL.fused_ce_dice(z, t, weights[L])
+        assert abs(float(res[0]) - g[f"ce{L}"]) < TOL * max(1.0, abs(g[f"ce{L}"])), L
+        assert abs(float(res[1]) - g[f"dice{L}"]) < TOL * max(1.0, abs(g[f"dice{L}"])), L
+        loss = loss + res[0] + res[1]
+        oh, _ = ops.predict_metrics(z.detach(), t, child=(L > 0), mask_pred=True)
+        onehots.append(oh)
+        # arg-max near-ties may flip a pixel: 1e-3 of the pixels
+        npx = batch * size * size
+        hist = torch.bincount(z.detach().argmax(1).reshape(-1), minlength=z.shape[1]).cpu().numpy()
+        assert np.abs(hist - g[f"argmax_hist{L}"]).sum() <= 2e-3 * npx, (L, hist, g[f"argmax_hist{L}"])
+        cnt = oh.sum((0, 2, 3)).cpu().numpy()
+        hit = (oh * (t == 1)).sum((0, 2, 3)).cpu().numpy()
+        assert np.abs(cnt - g[f"onehot_count{L}"]).sum() <= 2e-3 * npx and np.abs(hit - g[f"onehot_hit{L}"]).sum() <= 2e-3 * npx
+    cons = PL.hierarchical_consistency_loss(onehots, model.levels, model.parent_of)
+    assert abs(float(cons) - g["cons_onehot"]) < 2e-3
+    loss = loss + cons
+    assert abs(float(loss) - g["loss"]) < TOL * abs(g["loss"])
+    loss.backward()
+    counts = {f: _lib.launch_count(f, reset=True) for f in FAMILIES}
+    print(name, counts)
+    # the kernels of the headline step, under the default routing
+    assert counts["wgrad9"] > 0 and counts["f32"] + counts["f32_group"] < counts["ws"] + counts["ws_group"] + counts["sp_im2col"] + \
+        counts["sp_group"] + counts["patch_sp"] + counts["sp_pgroup"] + counts["sp_wide"], counts
+    if kind == "hrnet":
+        assert counts["ws_group"] >= 100 and counts["ws_canvas"] > 0, counts      # four-branch groups, canvas-tiled small branches
+        assert counts["sp_wide"] > 0 and counts["wgrad_sp_wide"] > 0, counts     # the 720-channel layer's wide bodies
+        assert counts["sp_im2col"] > 0 and counts["sp_group"] > 0 and counts["wgrad_sp_group"] > 0, counts
+    else:
+        assert counts["ws"] + counts["ws_group"] > 20, counts
+
+    # gradients: per-parameter L2 norms and seeded +-1 projections.  Yardstick = the reference evaluated in fp64; the product
+    # must be as close to it as the fp32 reference is (tests/test_grad_noise_gpu.py's form), and within 5e-3 of the fp32
+    # reference's norms outright where those are not noise
+    named = dict(model.named_parameters())
+    norms, projs = [], []
+    for n, p in named.items():
+        gr = p.grad.detach().double().reshape(-1).cpu().numpy()
+        norms.append(np.sqrt((gr * gr).sum()))
+        projs.append((gr * _projection_vector(n, gr.size)).sum())
+    norms, projs = np.array(norms), np.array(projs)
+    n32, n64, p32, p64 = g["grad_norms"], g["grad_norms64"], g["grad_projs"], g["grad_projs64"]
+    scale = np.maximum(n64, 1e-2 * n64.max())
+    e_prod, e_ref = np.abs(norms - n64) / scale, np.abs(n32 - n64) / scale
+    pe_prod, pe_ref = np.abs(projs - p64) / scale, np.abs(p32 - p64) / scale       # |projection| <= sqrt(numel) * norm: same scale family
+    print(f"{name}: norm err vs fp64 median {np.median(e_prod):.2e} (fp32 reference {np.median(e_ref):.2e}), "
+          f"max {e_prod.max():.2e} ({e_ref.max():.2e}); projection err median {np.median(pe_prod):.2e} ({np.median(pe_ref):.2e}), "
+          f"max {pe_prod.max():.2e} ({pe_ref.max():.2e})")
+    assert np.median(e_prod) <= 1.5 * np.median(e_ref) + 1e-5
+    assert np.percentile(e_prod, 90) <= 2.0 * np.percentile(e_ref, 90) + 1e-5
+    assert e_prod.max() <= max(3.0 * e_ref.max(), 5e-3), list(named)[int(np.argmax(e_prod))]
+    assert np.median(pe_prod) <= 1.5 * np.median(pe_ref) + 1e-5
+    assert np.percentile(pe_prod, 90) <= 2.0 * np.percentile(pe_ref, 90) + 1e-4
+    worst = int(np.argmax(np.abs(norms - n32) / np.maximum(n32, 1e-2 * n32.max())))
+    assert (np.abs(norms - n32) / np.maximum(n32, 1e-2 * n32.max()))[worst] < 5e-3, (list(named)[worst], norms[worst], n32[worst])
+    for key in g.files:
+        if key.startswith("grad::"):
+            got = named[key[6:]].grad.cpu().numpy()
+            assert np.abs(got - g[key]).max() < 5e-3 * np.abs(g[key]).max() + 2e-6, key
+    bufs = np.array([float(b.double().norm()) for _, b in model.named_buffers()])
+    assert np.max(np.abs(bufs - g["buf_norms"]) / np.maximum(g["buf_norms"], 1e-6)) < TOL
+
+
+def test_configs0_flat_unet_b2_128_tracks_the_oracle():
+    """BASELINE.json configs[0] as written: UNet donor, non-hierarchical (model_type 0), batch 2, 128 x 128, 7 classes -- two
+    full train steps (forward, metrics, CE + Dice, backward, AdamW) of the HIP path next to the CPU oracle, default routing"""
+    from oracle import models as OM
+    from oracle import train_step as OT
+    from hrseg_amd import _lib
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    from hrseg_amd.utils import synth
+    from hrseg_amd.utils.hierarchy import get_classes
+    tree = load_tree("class_tree_tl.json")
+    nleaf = [sum(get_classes(tree, full=False))]
+    assert nleaf == [7]
+    weights = synth.README_LEVEL_WEIGHTS_FLAT
+    xn, tn = synth.synthetic_batch(tree, 2, 128, seed=2, hierarchical=False)           # bench.py's configs[0] batch
+    x, target = torch.from_numpy(xn), torch.from_numpy(tn)
+    args = argparse.Namespace(model_type=0, model_select=0, num_classes=nleaf, level_weights=weights,
+                              level0_pretrain_epochs=None, batch_size=2)
+    om = build_model(OM, "unet", False, tree, 128)
+    oopt = torch.optim.AdamW(om.parameters(), lr=1e-4)
+    pm = build_model(PM, "unet", False, tree, 128).cuda()
+    popt = PT.FusedAdamW(pm, lr=[1e-4])
+    fns = [[PL.CrossEntropyLoss(), PL.SoftDiceLoss(num_classes=7)]]
+    pm.train()
+    _lib.launch_count(None, reset=True)
+    for step in range(2):
+        ref = OT.train_step(om, oopt, x, target, nleaf, weights, hierarchical=False, is_unet=True)
+        pm.train()
+        loss, cms = PT.train_step(pm, popt, x.cuda(), target.cuda(), fns, args, tree, [])
+        assert abs(float(loss) - ref["loss"].item()) < TOL * abs(ref["loss"].item()), step
+        vec = PT._metric_vectors(cms)
+        for k, v in ref["metrics"].items():
+            got = vec[k].cpu().numpy()
+            tol = 2e-3 if step == 0 else 7e-3
+            assert np.allclose(got, v, atol=tol), (step, k, got, v)
+        if step == 0:
+            pm.eval()
+            om.eval()
+            with torch.no_grad():
+                _, zo = om(x, type=0)
+                _, zp = pm(x.cuda(), type=0)
+            assert rel_err(zp.cpu().numpy(), zo.numpy()) < 3 * TOL        # (weights one AdamW step apart by rounding noise)
+            om.train()
+    assert _lib.launch_count(None) > 0
+    osd = om.state_dict()
+    for n, p in pm.state_dict().items():
+        a, b = p.detach().cpu().double(), osd[n].double()
+        if n.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 2
+        elif "running_" in n:
+            assert float((a - b).norm()) < 1e-2 * float(b.norm()) + 1e-5, n
+        else:
+            assert float((a - b).abs().max()) < 4.5e-4 + 1e-3 * float(b.abs().max()), n

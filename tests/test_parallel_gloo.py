@@ -1,4 +1,4 @@
-"""Gradient-sync bucket logic with world_size 2 on CPU (gloo): every flat-gradient element is
+"""Gradient-sync bucket logic with world_size 2 and 4 on CPU (gloo): every flat-gradient element is
 all-reduced exactly once, in reverse registration order, as the marks of the last backward level pass."""
 import os
 import types
@@ -60,17 +60,20 @@ def _worker(rank, world, port):
     # Dice under data parallelism: the divisor is the GLOBAL number of valid items (reference losses.py:64-66 on the
     # gathered batch).  Rank 0: two items, both valid; rank 1: two items, one all-ignored at this level.
     from hrseg_amd.Metrics.losses import global_batch_dice
-    item_dice = [[0.30, 0.50], [0.80]][rank]                      # per-item Dice values of the rank's valid items
+    # World 4 adds a rank without any valid item (its Dice term and gradient vanish, the others carry the whole mean).
+    items = {2: [[0.30, 0.50], [0.80]], 4: [[0.30, 0.50], [0.80], [], [0.10, 0.20, 0.60]]}[world]
+    item_dice = items[rank]                                       # per-item Dice values of the rank's valid items
     local = torch.tensor(item_dice, dtype=torch.float64, requires_grad=True)
-    res = [torch.zeros(()), local.mean().float(), torch.tensor(float(len(item_dice)))]
+    res = [torch.zeros(()), (local.sum() / max(len(item_dice), 1)).float(), torch.tensor(float(len(item_dice)))]
     term = global_batch_dice(res)
-    gathered = (0.30 + 0.50 + 0.80) / 3.0
+    flat_items = [v for r in items for v in r]
+    gathered = sum(flat_items) / len(flat_items)
     avg = term.detach().clone().double().reshape(1)
     dist.all_reduce(avg)
     assert abs(float(avg) / world - gathered) < 1e-6, (float(avg) / world, gathered)       # mean over ranks = gathered Dice
     term.backward()
-    # gradient averaged over the ranks: d(gathered)/d(item) = 1/3 for every valid item
-    assert torch.allclose(local.grad / world, torch.full_like(local, 1.0 / 3.0), atol=1e-6), local.grad
+    # gradient averaged over the ranks: d(gathered)/d(item) = 1/n_global for every valid item
+    assert torch.allclose(local.grad / world, torch.full_like(local, 1.0 / len(flat_items)), atol=1e-6), local.grad
     # no valid item anywhere: the term is zero, not NaN
     z = global_batch_dice([torch.zeros(()), torch.zeros((), requires_grad=True) * 1.0, torch.tensor(0.0)])
     assert float(z) == 0.0
@@ -80,6 +83,13 @@ def _worker(rank, world, port):
 def test_bucketed_allreduce_world2_gloo():
     port = 29500 + (os.getpid() % 1000)
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_bucketed_allreduce_world4_gloo():
+    """four ranks: bucket boundaries / completeness of the exchange, summed confusion counts, and the global Dice divisor
+    with one rank that holds no valid item at all"""
+    port = 30600 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(4, port), nprocs=4, join=True)
 
 
 def test_single_process_is_a_noop():
