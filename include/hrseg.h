@@ -130,7 +130,7 @@ int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* 
 /* launches issued so far by kernel family ("ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32",
  * "f32_group", "wgrad_sp", "wgrad_sp_group", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide"; NULL = all); reset != 0
  * zeroes what it returns.  "ws_canvas" counts PROBLEMS (not launches, not part of the NULL total) that a "ws" / "ws_group"
- * launch tiled as one canvas of side-by-side images, "wgrad_sp_t5" the "wgrad_sp" launches on 80 x 80 tiles ("wgrad_sp_wide": the wide-tile weight-gradient kernel, a family of its own), "wgrad9_wide" the "wgrad9" calls in which some problems ran the wide nine-tap form.  The parity tests use it to prove which kernels a case ran. */
+ * launch tiled as one canvas of side-by-side images, "wgrad_sp_t5" the "wgrad_sp" launches on 80 x 80 tiles ("wgrad_sp_wide": the wide-tile weight-gradient kernel, a family of its own).  The parity tests use it to prove which kernels a case ran. */
 long hrseg_launch_count(const char* family, int reset);
 /* tile-plan overrides and A/B switches for the sweep tools under tools/ (value 0 = automatic plan).  Keys: igemm_wtm,
  * igemm_kc, igemm_db, igemm_ksplit, group_wtm, wgrad_pix, wgrad_db, wgrad_blocks, wgrad_group_mult,
@@ -139,8 +139,7 @@ long hrseg_launch_count(const char* family, int reset);
  * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_bf16 (0: the BF16 arithmetic stays off the wave-specialised kernels), small_cin3 (0: the 3-channel first layer on the generic
  * Cin <= 8 kernels), sp_ws_canvas (0: tile every image on its own, never the batch as one
  * canvas), sp_img (0: block-synchronous kernels
- * split their weights on the fly); wgrad9, wgrad9_blocks, wgrad9_wide, wgrad9_split4 (nine-tap weight gradient; 1: the wide form resp. the six-wave form of the
- * 64-channel tiling, both measured slower, default 0); wgrad_group_sp (0: grouped tap-per-block
+ * split their weights on the fly); wgrad9 (0: never the nine-tap weight gradient), wgrad9_blocks (its target block count); wgrad_group_sp (0: grouped tap-per-block
  * weight gradients stay on the fp32 kernel), wgrad_sp_t5 (0: no 80 x 80 tiles for the wide layers), wgrad_sp_wide (0: never the wide-tile weight-gradient body); deterministic (1: single-adder
  * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
  * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
@@ -198,8 +197,7 @@ int hrseg_bn_bwd_apply(const double* partial, int nchunks, const float* dz, int 
                        long npix, int C, int eval_mode, hrseg_stream_t stream);
 
 /* Grouped forms: n (1..8) independent BatchNorm problems in three launches (statistics, finalize,
- * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward -- two each when
- * the caller provides the `acc` accumulators (statistics + finalize, reduce + finalize fused). */
+ * apply; eval: coefficients, apply) resp. (reduce, finalize, apply) for the backward. */
 typedef struct {
   const float* y; int ldy; long npix; int C;       /* conv output [npix][C]                      */
   const float* gamma; const float* beta;
@@ -225,17 +223,6 @@ typedef struct {
                                                         equal shards between the statistics and the finalize
                                                         phase, so the statistics cover stat_ranks*npix pixels
                                                         (0 or 1 = this rank only, the reference's behaviour)  */
-  double* acc;                                       /* optional, training: 16*2*C + 1 doubles that are ZERO on entry
-                                                        (the caller zeroes them once; every call leaves them zero).
-                                                        Given for every problem of a call that runs statistics and
-                                                        finalize together (phases 3 or 7, stat_ranks <= 1), and not
-                                                        in deterministic mode, the two are ONE launch: the blocks
-                                                        add their sums into 16 accumulator rows and the block that
-                                                        arrives last finishes the layer.  The order of those adds
-                                                        is not fixed (last bits of the fp64 sums vary run to run).
-                                                        Measured slower than the three launches on the train steps
-                                                        of this repo (bn_elem.hip); the Python side passes it only
-                                                        on request                                                 */
 } hrseg_bn_fwd_t;
 int hrseg_bn_fwd_group(int n, const hrseg_bn_fwd_t* problems, int training, hrseg_stream_t stream);
 /* the same in phases (bit 0 statistics, bit 1 finalize / eval coefficients, bit 2 apply; 7 = all): a caller that
@@ -266,9 +253,6 @@ typedef struct {
                                                         phase; the finalize divides them by it, so that the batch
                                                         means are global and dgamma / dbeta receive this rank's
                                                         share (0 or 1 = this rank only)                      */
-  double* acc;                                       /* optional: 16*max(nseg,1)*2*C + 1 doubles, ZERO on entry and
-                                                        left zero; reduce and finalize in one launch, as for
-                                                        hrseg_bn_fwd_t.acc (`partial` still receives the totals)   */
 } hrseg_bn_bwd_t;
 int hrseg_bn_bwd_group(int n, const hrseg_bn_bwd_t* problems, int eval_mode, hrseg_stream_t stream);
 /* phases: bit 0 reduce, bit 1 finalize, bit 2 apply (7 = all), see hrseg_bn_fwd_group_phases */

@@ -44,14 +44,14 @@ class BnFwd(C.Structure):
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
                 ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
-                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("stat_ranks", _i), ("acc", _p)]
+                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("stat_ranks", _i)]
 
 
 class BnBwd(C.Structure):
     """hrseg_bn_bwd_t"""
     _fields_ = [("dz", _p), ("lddz", _i), ("z", _p), ("ldz", _i), ("relu", _i), ("y", _p), ("ldy", _i), ("coef", _p),
                 ("dgamma", _p), ("dbeta", _p), ("dy", _p), ("lddy", _i), ("dres", _p), ("lddres", _i),
-                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("dy_absmax", _p), ("nseg", _i), ("relu_mask", _p), ("sum_ranks", _i), ("acc", _p)]
+                ("dres_accumulate", _i), ("npix", _l), ("C", _i), ("partial", _p), ("nchunks", _i), ("dy_absmax", _p), ("nseg", _i), ("relu_mask", _p), ("sum_ranks", _i)]
 
 
 # name -> argtypes, exactly the prototypes of include/hrseg.h
@@ -212,7 +212,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 10    # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 11    # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

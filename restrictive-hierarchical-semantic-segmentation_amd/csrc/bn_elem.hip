@@ -671,7 +671,6 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 // atomics into one accumulator: blocks finishing together serialise on 2*C addresses; sixteen accumulator rows and
 // a last block that only adds those up (bn_last_block below, kept as an opt-in): +0.8 ms per step -- see DESIGN.md.)
 #define BN_MAXG 8
-#define BN_ACC_R 16
 struct BnGroupHdr { int n; int blk_end[BN_MAXG]; };
 __device__ __forceinline__ int bn_find(const BnGroupHdr& h, int& local, int& nblk) {
   int g = 0;
@@ -689,8 +688,7 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
                                            int ldz, int relu, const float* __restrict__ yy, int ldy,
                                            const float* __restrict__ coef, long npix, int C,
                                            double* __restrict__ partial, int chunk, int nchunks, bool bwd,
-                                           double* red, int nseg = 1, const unsigned char* __restrict__ bmask = nullptr,
-                                           double* __restrict__ acc = nullptr) {
+                                           double* red, int nseg = 1, const unsigned char* __restrict__ bmask = nullptr) {
   // forward: sums of a0 and a0^2; backward: sums of g and g*xhat with g = a0 * (zmask > 0 if relu)
   // nseg > 1: the pixel range is nseg equal segments (the batched level passes); a chunk never
   // straddles two segments (nchunks is a multiple of nseg)
@@ -764,60 +762,9 @@ __device__ __forceinline__ void stats_body(const float* __restrict__ a0, int ld0
       a += red[t * 8 + (c & 3)];
       b += red[t * 8 + 4 + (c & 3)];
     }
-    if (acc) {                  // fused finalize: one of BN_ACC_R accumulator rows per (segment, sum), see bn_last_block
-      double* row = acc + ((size_t)(chunk & (BN_ACC_R - 1)) * nseg + seg) * 2 * C;
-      __hip_atomic_fetch_add(row + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(row + C + c, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      partial[((size_t)chunk * 2 + 0) * C + c] = a;
-      partial[((size_t)chunk * 2 + 1) * C + c] = b;
-    }
+    partial[((size_t)chunk * 2 + 0) * C + c] = a;
+    partial[((size_t)chunk * 2 + 1) * C + c] = b;
   }
-}
-
-// Fused finalize (hrseg_bn_*_t.acc): the statistics blocks ADD their per-channel sums into BN_ACC_R rows of fp64 accumulators
-// (block b into row b % 16: ~60 adds per address for a 1000-block launch, where one row would serialise them all) and count
-// themselves in; the block that arrives LAST adds the 16 rows up, finishes the layer (coefficients and running statistics,
-// resp. totals and dgamma / dbeta) and stores zeros back, so the accumulators are zero again at every kernel boundary: the
-// caller zeroes them once.  This removes the finalize launch of the three-launch form (a 6 us kernel plus a kernel boundary,
-// 220 times per HRNet step).  The order in which the blocks' sums meet is not fixed: results vary in the last bits of the
-// fp64 sums from run to run, so the deterministic mode keeps the three-launch form, whose order is fixed.
-// MEASURED (round 3, same box): HRNet step 54.45 ms fused vs 53.63 ms three-launch, UNet 42.78 vs 42.84 -- the atomics' round
-// trip at the end of every block of a kernel whose blocks all run at once, plus the last block's serial finish, cost more
-// than the launch they save.  The callers therefore pass acc only on request (ops.py: HRSEG_BN_FUSED_FINALIZE=1).
-// acc layout: [BN_ACC_R][nseg][2][C] doubles, then the arrival counter (one 8-byte slot).
-__device__ __forceinline__ bool bn_last_block(double* acc, int nseg, int C, int nblk) {
-  // No fences: a release / acquire pair at agent scope writes back and invalidates the XCD's whole L2 -- per block of a
-  // bandwidth-bound kernel that cost 100 us per launch when measured.  None is needed: the accumulators are only ever touched by
-  // agent-scope atomics (adds, loads, stores), which are performed at the memory side and never cached; what has to hold is
-  // the ORDER "every add of the block performed, then the block counts itself in", and that is the wait below (the adds have
-  // been acknowledged) in front of the barrier in front of the count.  The last block learns that it is last from the value its
-  // own add returns, and its loads are issued after that.
-  __shared__ int last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned* counter = reinterpret_cast<unsigned*>(acc + (size_t)BN_ACC_R * nseg * 2 * C);
-  if (threadIdx.x == 0)
-    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);
-  __syncthreads();
-  return last;
-}
-// the sum of slot (seg, k) of channel c over the accumulator rows, which are left zero
-__device__ __forceinline__ double bn_acc_take(double* acc, int nseg, int C, int seg, int k, int c) {
-  double t = 0.0;
-#pragma unroll 1
-  for (int r0 = 0; r0 < BN_ACC_R; r0 += 8) {          // eight loads in flight (all sixteen cost the statistics kernel occupancy)
-    double v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      v[r] = __hip_atomic_load(acc + (((size_t)(r0 + r) * nseg + seg) * 2 + k) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      t += v[r];
-      __hip_atomic_store(acc + (((size_t)(r0 + r) * nseg + seg) * 2 + k) * C + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  return t;
 }
 
 __device__ __forceinline__ void bn_finalize_channel(const hrseg_bn_fwd_t& p, int c, double s, double ss) {
@@ -857,23 +804,6 @@ __global__ __launch_bounds__(256) void bn_stats_group_kernel(BnFwdG g) {
   int local, nblk;
   const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
   stats_body<false>(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1);
-}
-
-__global__ __launch_bounds__(256) void bn_stats_fin_group_kernel(BnFwdG g) {
-  __shared__ double red[256 * 8];
-  int local, nblk;
-  const hrseg_bn_fwd_t& p = g.p[bn_find(g.h, local, nblk)];
-  stats_body<false>(p.y, p.ldy, nullptr, 0, 0, nullptr, 0, nullptr, p.npix, p.C, p.partial, local, p.nchunks, false, red, 1,
-                    nullptr, p.acc);
-  if (!bn_last_block(p.acc, 1, p.C, nblk)) return;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    const double s = bn_acc_take(p.acc, 1, p.C, 0, 0, c), ss = bn_acc_take(p.acc, 1, p.C, 0, 1, c);
-    bn_finalize_channel(p, c, s, ss);
-  }
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p.acc + (size_t)BN_ACC_R * 2 * p.C), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p.num_batches_tracked) *(long long*)p.num_batches_tracked += (p.stat_updates > 1 ? p.stat_updates : 1);
-  }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_group_kernel(BnFwdG g) {
@@ -936,33 +866,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(BnBwdG g) {
   if (local == 0 && threadIdx.x < 64 && p.dy_absmax) p.dy_absmax[threadIdx.x] = 0.f;
   stats_body<MASK>(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, p.C, p.partial, local, p.nchunks, true, red,
                    nseg, p.relu_mask);
-}
-
-template <bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_fin_group_kernel(BnBwdG g) {
-  __shared__ double red[256 * 8];
-  int local, nblk;
-  const hrseg_bn_bwd_t& p = g.p[bn_find(g.h, local, nblk)];
-  const int nseg = p.nseg > 1 ? p.nseg : 1, C = p.C;
-  if (local == 0 && threadIdx.x < 64 && p.dy_absmax) p.dy_absmax[threadIdx.x] = 0.f;
-  stats_body<MASK>(p.dz, p.lddz, p.z, p.ldz, p.relu, p.y, p.ldy, p.coef, p.npix, C, p.partial, local, p.nchunks, true, red,
-                   nseg, p.relu_mask, p.acc);
-  if (!bn_last_block(p.acc, nseg, C, nblk)) return;
-  double* totals = p.partial + (size_t)p.nchunks * 2 * C;      // [nseg][2][C], read by the apply kernel
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double s_all = 0.0, sx_all = 0.0;
-    for (int seg = 0; seg < nseg; ++seg) {
-      const double s = bn_acc_take(p.acc, nseg, C, seg, 0, c), sx = bn_acc_take(p.acc, nseg, C, seg, 1, c);
-      totals[(size_t)seg * 2 * C + c] = s;
-      totals[(size_t)seg * 2 * C + C + c] = sx;
-      s_all += s;
-      sx_all += sx;
-    }
-    if (p.dgamma) p.dgamma[c] += (float)sx_all;
-    if (p.dbeta) p.dbeta[c] += (float)s_all;
-  }
-  if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p.acc + (size_t)BN_ACC_R * nseg * 2 * C), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_group_kernel(BnBwdG g) {
@@ -1355,13 +1258,7 @@ extern "C" int hrseg_bn_fwd_group_phases(int n, const hrseg_bn_fwd_t* probs, int
     g.p[i] = probs[i];
   }
   int end = 0;
-  bool fused = training && (phases & 3) == 3 && !hrseg_g_deterministic;       // statistics + finalize in one launch
-  for (int i = 0; i < n; ++i) fused = fused && probs[i].acc && probs[i].stat_ranks <= 1;
-  if (fused) {
-    for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-    hipLaunchKernelGGL(bn_stats_fin_group_kernel, dim3(end), dim3(256), 0, st, g);
-    HRSEG_LAUNCH_CHECK("bn_stats_fin_group");
-  } else if (training) {
+  if (training) {
     if (phases & 1) {
       for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
       hipLaunchKernelGGL(bn_stats_group_kernel, dim3(end), dim3(256), 0, st, g);
@@ -1407,23 +1304,15 @@ extern "C" int hrseg_bn_bwd_group_phases(int n, const hrseg_bn_bwd_t* probs, int
     g.p[i] = p;
   }
   int end = 0;
-  bool masked = false, fused = (phases & 3) == 3 && !hrseg_g_deterministic;    // reduce + finalize in one launch
-  for (int i = 0; i < n; ++i) {
-    masked = masked || (probs[i].relu && probs[i].relu_mask);
-    fused = fused && probs[i].acc && probs[i].sum_ranks <= 1;
-  }
-  if (fused) {
-    for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
-    if (masked) hipLaunchKernelGGL(bn_bwd_reduce_fin_group_kernel<true>, dim3(end), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(bn_bwd_reduce_fin_group_kernel<false>, dim3(end), dim3(256), 0, st, g);
-    HRSEG_LAUNCH_CHECK("bn_bwd_reduce_fin_group");
-  } else if (phases & 1) {
+  bool masked = false;
+  for (int i = 0; i < n; ++i) masked = masked || (probs[i].relu && probs[i].relu_mask);
+  if (phases & 1) {
     for (int i = 0; i < n; ++i) { end += probs[i].nchunks; g.h.blk_end[i] = end; }
     if (masked) hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<true>, dim3(end), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<false>, dim3(end), dim3(256), 0, st, g);
     HRSEG_LAUNCH_CHECK("bn_bwd_reduce_group");
   }
-  if (!fused && (phases & 2)) {
+  if (phases & 2) {
     end = 0;
     for (int i = 0; i < n; ++i) { end += ceil_div(probs[i].C, 16); g.h.blk_end[i] = end; }
     hipLaunchKernelGGL(bn_bwd_finalize_group_kernel, dim3(end), dim3(256), 0, st, g);

@@ -32,15 +32,15 @@
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
 enum { CNT_WS = 0, CNT_WS_GROUP, CNT_PATCH_SP, CNT_SP_IM2COL, CNT_SP_PGROUP, CNT_SP_GROUP, CNT_F32, CNT_F32_GROUP, CNT_WGRAD_SP,
-       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_WGRAD_SP_WIDE, CNT_WGRAD9_WIDE, CNT_N };
+       CNT_WGRAD_F32, CNT_WGRAD_F32_GROUP, CNT_WGRAD9, CNT_SMALL_CIN, CNT_SP_WIDE, CNT_WS_CANVAS, CNT_WGRAD_SP_GROUP, CNT_WGRAD_SP_T5, CNT_WGRAD_SP_WIDE, CNT_N };
 static const char* const g_cnt_names[CNT_N] = {"ws", "ws_group", "patch_sp", "sp_im2col", "sp_pgroup", "sp_group", "f32", "f32_group",
-                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5", "wgrad_sp_wide", "wgrad9_wide"};
+                                               "wgrad_sp", "wgrad_f32", "wgrad_f32_group", "wgrad9", "small_cin", "sp_wide", "ws_canvas", "wgrad_sp_group", "wgrad_sp_t5", "wgrad_sp_wide"};
 static long g_cnt[CNT_N];
 extern "C" long hrseg_launch_count(const char* family, int reset) {
   long total = 0;
   for (int i = 0; i < CNT_N; ++i)
-    if (family ? !strcmp(family, g_cnt_names[i]) : (i != CNT_WS_CANVAS && i != CNT_WGRAD_SP_T5 && i != CNT_WGRAD9_WIDE)) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
-  if (!family && reset) g_cnt[CNT_WS_CANVAS] = g_cnt[CNT_WGRAD_SP_T5] = g_cnt[CNT_WGRAD9_WIDE] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
+    if (family ? !strcmp(family, g_cnt_names[i]) : (i != CNT_WS_CANVAS && i != CNT_WGRAD_SP_T5)) { total += g_cnt[i]; if (reset) g_cnt[i] = 0; }
+  if (!family && reset) g_cnt[CNT_WS_CANVAS] = g_cnt[CNT_WGRAD_SP_T5] = 0;      // "ws_canvas" counts PROBLEMS laid out as a canvas inside ws / ws_group launches
   return total;
 }
 
@@ -775,8 +775,6 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, int prec, hipStream_t st) {
 // --------------------------------------------------------------------------- nine-tap weight gradient (workspace + ordered reduce)
 static int g_wg9_blocks = 0;           // hrseg_tune "wgrad9_blocks": target blocks per problem (0 = 256)
 static int g_wg9 = 1;                  // hrseg_tune "wgrad9": 0 = never use the nine-tap kernel
-static int g_wg9_ws = 0;               // hrseg_tune "wgrad9_ws": 1 = the role-split nine-tap body (measured slower)
-static int g_wg9_xcd = 0;              // hrseg_tune "wgrad9_xcd": 1 = XCD-contiguous block order in the nine-tap kernels
 // tiles per side of the dW tile (3: channels multiple of 48, 4: multiple of 64), 0 = not a nine-tap case
 static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   if (!g_wg9 || s.ksize != 3 || s.stride != 1 || sp_pieces(s.precision) == 0) return 0;
@@ -785,77 +783,28 @@ static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   return 0;
 }
 // `group_n` problems share the launch: two blocks fit a CU, so the launch's blocks should fill whole rounds of 512 --
-// 256 per problem for one, two or four problems, 1024 / 3 for three (measured on the three-branch group: 139 -> 127 us);
-// `lone`: the one narrow problem of a call whose other problems take the wide form (its launch has the chip to itself: 512)
-static void wgrad9_geometry(const hrseg_conv_shape_t& s, Wgrad9Args& a) {
+// 256 per problem for one, two or four problems, 1024 / 3 for three (measured on the three-branch group: 139 -> 127 us)
+static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n) {
   a.B = s.B; a.H = s.Hi; a.W = s.Wi; a.Cin = s.Cin; a.Cout = s.Cout; a.ldx = s.ldx; a.lddy = s.ldy;
   a.tiles_x = ceil_div(s.Wi, 16); a.tiles_y = ceil_div(s.Hi, 4);
   a.ntiles = s.B * a.tiles_x * a.tiles_y;
-}
-static void wgrad9_set_chunks(Wgrad9Args& a, int chunks) {
+  const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
+  const int target = g_wg9_blocks ? g_wg9_blocks : (group_n == 3 ? 341 : 256);
+  int chunks = (group_n == 3 && !g_wg9_blocks) ? target / npairs : ceil_div(target, npairs);
   if (chunks > a.ntiles) chunks = a.ntiles;
   if (chunks < 1) chunks = 1;
   a.per = ceil_div(a.ntiles, chunks);
   a.nchunks = ceil_div(a.ntiles, a.per);
 }
-static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n, bool lone = false) {
-  wgrad9_geometry(s, a);
-  const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
-  const int target = g_wg9_blocks ? g_wg9_blocks : lone ? 512 : (group_n == 3 ? 341 : 256);
-  wgrad9_set_chunks(a, (group_n == 3 && !g_wg9_blocks) ? target / npairs : ceil_div(target, npairs));
-}
-// The wide form (wgrad9_wide_body): kind 1 = 96 x 48 block tiles (output x input channels) for the 48-channel tiling.  (The
-// 64-channel tiling keeps 192 accumulator registers per wave and only fits with one three-wave block per CU: no wide form.)
-// MEASURED SLOWER and therefore off by default (same box, tools/conv_census.py): three-branch group 120.1 -> 129.2 us, four-branch
-// 158.6 -> 165.6 us, two-branch 71.3 -> 91.0 us, the step 52.0 -> 52.35 ms.  The staging per MFMA does drop by 31 %, but one
-// six-wave block per CU passes every barrier in lock-step, where two independent three-wave blocks drift apart and overlap one
-// block's staging with the other's MFMAs; and the 48-channel branch needs a launch of its own.
-static int g_wg9_wide = 0;             // hrseg_tune "wgrad9_wide": 1 = 96-channel and wider problems on the wide form
-// kind 2 (hrseg_tune "wgrad9_split4"): the 64-channel tiling with SIX waves per block -- same 64 x 64 block tile, pixel chunks
-// and workspace as wgrad9_sp_group_kernel4, but every kernel row's 4 x 4 tiles are shared by two waves (4 x 2 each; 204
-// registers, bit-identical results).  Three waves per CU leave one SIMD idle, so this looked like free MFMA capacity; MEASURED:
-// UNet step 42.53 -> 43.91 ms, HRNet 52.15 -> 52.32 (three / two runs each, same box).  Off by default.
-static int g_wg9_split4 = 0;
-static const int WG9W_CA[3] = {0, 96, 64}, WG9W_CB[3] = {0, 48, 64};
-static int wgrad9_wide_kind(const hrseg_conv_shape_t& s, int tnk) {
-  if (sp_pieces(s.precision) != 4) return 0;
-  if (tnk == 4) return g_wg9_split4 ? 2 : 0;
-  if (!g_wg9_wide) return 0;
-  return (s.Cout % WG9W_CA[1] == 0 && s.Cin % WG9W_CB[1] == 0) ? 1 : 0;
-}
-// plan of one call: which problems take the wide form, and every problem's pixel chunks.  The wide launch has ONE round of
-// 256 six-wave blocks (one per CU), shared among its problems in proportion to their tile-pair counts.
-struct Wg9Plan { int tnk, n_narrow, n_wide, kind[WG9_MAXG]; Wgrad9Args a[WG9_MAXG]; };
+// plan of one call: every problem's pixel chunks (all problems share one tiling and one arithmetic)
+struct Wg9Plan { int tnk; Wgrad9Args a[WG9_MAXG]; };
 static bool wgrad9_plan_all(int n, const hrseg_conv_shape_t* shapes, Wg9Plan& pl) {
   if (n < 1 || n > WG9_MAXG) return false;
   pl.tnk = wgrad9_tnk(shapes[0]);
   if (!pl.tnk) return false;
-  pl.n_narrow = pl.n_wide = 0;
-  long work[WG9_MAXG], total = 0;
   for (int i = 0; i < n; ++i) {
     if (wgrad9_tnk(shapes[i]) != pl.tnk || shapes[i].precision != shapes[0].precision) return false;
-    pl.kind[i] = wgrad9_wide_kind(shapes[i], pl.tnk);
-    if (pl.kind[i]) {
-      wgrad9_geometry(shapes[i], pl.a[i]);
-      work[i] = (long)pl.a[i].ntiles * (shapes[i].Cout / WG9W_CA[pl.kind[i]]) * (shapes[i].Cin / WG9W_CB[pl.kind[i]]);
-      total += work[i];
-      ++pl.n_wide;
-    } else {
-      ++pl.n_narrow;
-    }
-  }
-  for (int i = 0; i < n; ++i) {
-    if (pl.kind[i] == 2) {               // the narrow kernel's work list, run by six-wave blocks
-      wgrad9_plan(shapes[i], pl.tnk, pl.a[i], n);
-      continue;
-    }
-    if (!pl.kind[i]) {
-      wgrad9_plan(shapes[i], pl.tnk, pl.a[i], pl.n_narrow, pl.n_narrow == 1 && pl.n_wide > 0 && pl.tnk == 3);
-      continue;
-    }
-    const int npairs = (shapes[i].Cout / WG9W_CA[pl.kind[i]]) * (shapes[i].Cin / WG9W_CB[pl.kind[i]]);
-    const long blocks = g_wg9_blocks ? g_wg9_blocks : (256 * work[i] + total / 2) / total;
-    wgrad9_set_chunks(pl.a[i], (int)((blocks + npairs / 2) / npairs));
+    wgrad9_plan(shapes[i], pl.tnk, pl.a[i], n);
   }
   return true;
 }
@@ -873,12 +822,10 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
   Wg9Plan pl;
   if (!wgrad9_plan_all(n, shapes, pl)) return HRSEG_ERR_UNSUPPORTED;      // (the caller asked wgrad9_ws_bytes first)
   const int tnk = pl.tnk;
-  Wgrad9Group gn, gw;                  // narrow and wide launches of this call; one reduce for all problems
+  Wgrad9Group g;
   Wgrad9Reduce r;
-  gn.n = gw.n = 0;
-  r.n = n;
-  gn.xcd = gw.xcd = g_wg9_xcd;
-  int endn = 0, endw = 0, rend = 0, wkind = 0;
+  g.n = r.n = n;
+  int end = 0, rend = 0;
   for (int i = 0; i < n; ++i) {
     Wgrad9Args& a = pl.a[i];
     a.x = x[i]; a.dy = dy[i]; a.ws = ws;
@@ -886,29 +833,16 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
     HRSEG_CHECK_ARG((double)shapes[i].Hi * shapes[i].Wi * (double)(shapes[i].ldx > shapes[i].ldy ? shapes[i].ldx : shapes[i].ldy) * 4.0 < 4294967296.0,
                     "wgrad9: one image exceeds the 4 GB buffer-offset range");
     const long elems = (long)shapes[i].Cout * 9 * shapes[i].Cin;
-    if (pl.kind[i]) {
-      wkind = pl.kind[i];
-      endw += (shapes[i].Cout / WG9W_CA[wkind]) * (shapes[i].Cin / WG9W_CB[wkind]) * a.nchunks;
-      gw.blk_end[gw.n] = endw;
-      gw.a[gw.n++] = a;
-    } else {
-      endn += (shapes[i].Cout / (16 * tnk)) * (shapes[i].Cin / (16 * tnk)) * a.nchunks;
-      gn.blk_end[gn.n] = endn;
-      gn.a[gn.n++] = a;
-    }
+    end += (shapes[i].Cout / (16 * tnk)) * (shapes[i].Cin / (16 * tnk)) * a.nchunks;
+    g.blk_end[i] = end;
+    g.a[i] = a;
     r.ws[i] = ws; r.dw[i] = dw[i]; r.nchunks[i] = a.nchunks; r.n4[i] = elems / 4;
     rend += (int)((elems / 4 + 31) / 32 < 2048 ? (elems / 4 + 31) / 32 : 2048);
     r.blk_end[i] = rend;
     ws += (size_t)a.nchunks * elems;
   }
   ++g_cnt[CNT_WGRAD9];
-  if (gn.n)
-    if (int e = launch_wgrad9_kernels(ns, tnk, gn, endn, r, 0, st, g_wg9_ws)) return e;
-  if (gw.n) {
-    ++g_cnt[CNT_WGRAD9_WIDE];
-    if (int e = launch_wgrad9_wide(wkind, gw, endw, st)) return e;
-  }
-  return launch_wgrad9_reduce(r, rend, st);
+  return launch_wgrad9_kernels(ns, tnk, g, end, r, rend, st);
 }
 
 // --------------------------------------------------------------------------- weight transpose
@@ -1146,7 +1080,6 @@ extern "C" int hrseg_conv_fwd(const float* x, const float* w, const float* bias,
   hipStream_t st = (hipStream_t)stream;
   HRSEG_CHECK_ARG(s->Cout % 16 == 0 || s->Cin <= HRSEG_SMALL_CIN_MAX, "hrseg_conv_fwd: Cout %d not a multiple of 16", s->Cout);
   if (s->Cin <= HRSEG_SMALL_CIN_MAX) {
-    const long M = (long)s->B * s->Ho * s->Wo;
     launch_small_cin_fwd(x, w, bias, y, s, st);
     ++g_cnt[CNT_SMALL_CIN];
     HRSEG_LAUNCH_CHECK("conv_small_cin_fwd");
@@ -1318,7 +1251,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_ws", &g_wg9_ws}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"wgrad9_wide", &g_wg9_wide}, {"wgrad9_split4", &g_wg9_split4}, {"sp_wide_min_blocks", &g_spw_min_blocks}, {"wgrad9_xcd", &g_wg9_xcd},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

@@ -118,9 +118,7 @@ int launch_weight_images(const struct WeightImageGroup& g, int nblocks, hipStrea
 int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, int tiles, hipStream_t st);     // conv_wgrad_sp.hip
 int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st);
 int launch_wgrad_spw_kernel(const WgradArgs& a, int gx, int tiles, hipStream_t st);
-int launch_wgrad9_kernels(int ns, int tnk, const struct Wgrad9Group& g, int nblocks, const struct Wgrad9Reduce& r, int rblocks, hipStream_t st, int ws);
-int launch_wgrad9_wide(int kind, const Wgrad9Group& g, int nblocks, hipStream_t st);
-int launch_wgrad9_reduce(const Wgrad9Reduce& r, int rblocks, hipStream_t st);
+int launch_wgrad9_kernels(int ns, int tnk, const struct Wgrad9Group& g, int nblocks, const struct Wgrad9Reduce& r, int rblocks, hipStream_t st);
 int check_wgrad_span(const WgradArgs& a);
 #define HRSEG_SMALL_CIN_MAX 8
 void launch_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, const hrseg_conv_shape_t* s, hipStream_t st);  // conv_small.hip

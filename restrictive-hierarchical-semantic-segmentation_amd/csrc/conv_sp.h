@@ -1378,8 +1378,12 @@ __device__ __forceinline__ void igemm_patch_sp_body(const IgemmArgs& p, unsigned
   }
 }
 
+// two blocks (2 waves per SIMD) per CU where the instance fits: the bf16x3 instances (three pieces of every fragment and of
+// the staging registers) and the 96 x 64 fp16x2 / bf16x2 tilings need more than 256 registers for that and run one block per CU
+constexpr int sp_patch_min_waves(int ns, int wtn, int cs) { return (ns == 3 || (wtn == 6 && cs == 4)) ? 1 : 2; }
 template <int NS, int TH, int WTN, int CS, int FLIP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_patch_sp_kernel(IgemmArgs p, int ntotal) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sp_patch_min_waves(NS, WTN, CS), 2)))
+void igemm_patch_sp_kernel(IgemmArgs p, int ntotal) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchLds<NS, TH, WTN, CS>::BYTES];
   // a block owns `chunk` consecutive tiles (neighbours in x share halo columns: L2 hits in time)
   const int chunk = (ntotal + gridDim.x - 1) / gridDim.x;
@@ -1858,7 +1862,8 @@ __global__ __launch_bounds__(512) void igemm_patch_ws_group_kernel(IgemmGroup gr
 // grouped launch whose problems run either body (the parallel HRNet branches: the wide high-resolution
 // branches take the halo-patch body, the small low-resolution ones the im2col body with split-K)
 template <int NS, int WTM, int WTN, int CS, int FLIP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_sp_pgroup_kernel(IgemmGroup grp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sp_patch_min_waves(NS, WTN, CS), 2)))
+void igemm_sp_pgroup_kernel(IgemmGroup grp) {
   constexpr int A = SpPatchLds<NS, 8, WTN, CS>::BYTES, B = SpLds<NS, WTN>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[A > B ? A : B];
   int gi = 0;
@@ -2035,170 +2040,15 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
           out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
 }
 
-// ---- role-split form of the nine-tap weight gradient (fp16x2).  In wgrad9_sp_body every wave alternates ~550 staging
-// instructions (loads, splits, ds_writes) with its 162 MFMAs per tile, and 1.5 waves per SIMD do not hide that (MFMA-busy
-// 0.39).  Here a 384-thread block splits the roles as the wave-specialised forward body does: waves 0-2 (kernel rows) are
-// CONSUMERS and run only the MFMA section on one of TWO image buffers; waves 3-5 are PRODUCERS and stage the next tile into
-// the other buffer (its global loads were issued a whole tile earlier).  ONE barrier per tile: at barrier t the producers
-// have finished storing tile t and the consumers have finished computing tile t-1, so after it the consumers read buffer
-// t&1 while the producers overwrite buffer (t+1)&1.  Both roles pass the same number of barriers.  Per-accumulator product
-// order is that of wgrad9_sp_body: results are bit-identical (tests/test_ws_gpu.py).
-template <int NS, int TNK>
-__device__ __forceinline__ void wgrad9_ws_body(const Wgrad9Args& p, unsigned char* lds, const int pair, const int chunk) {
-  using L = SpWgrad9Lds<NS, TNK>;
-  constexpr int S = L::S, PIECE = L::PIECE, XBASE = L::DYPIX * S, BUF = L::BYTES;
-  constexpr int GPP = TNK * 4;
-  constexpr int NT = 192, PR = NT / GPP;
-  constexpr int DY_LOADS = (L::DYPIX + PR - 1) / PR, X_LOADS = (L::XPIX + PR - 1) / PR, LOADS = DY_LOADS + X_LOADS;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool consumer = wave < 3;
-  const int lane = threadIdx.x & 63;
-  const int nkt = p.Cin / (16 * TNK);
-  const int ct = pair / nkt, kt = pair - ct * nkt;
-  const int n0 = ct * 16 * TNK, k0 = kt * 16 * TNK;
-  const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
-  float dyscale, dyinv;
-  sp_pow2_scale(p.dymax, dyscale, dyinv);
-
-  if (!consumer) {
-    const int tid = threadIdx.x - 192;
-    f32x4 rg[LOADS];
-    const int pix0 = tid / GPP, gq = tid - pix0 * GPP;
-    const bool swork = pix0 < PR;
-    auto tile_load = [&](int t) {
-      const int tx = t % p.tiles_x;
-      int r = t / p.tiles_x;
-      const int ty = r % p.tiles_y, b = r / p.tiles_y;
-      const int y0 = ty * 4, x0 = tx * 16;
-      const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
-      const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
-#pragma unroll
-      for (int i = 0; i < DY_LOADS; ++i) {
-        const int pix = pix0 + PR * i;
-        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
-        const bool ok = swork & (pix < L::DYPIX) & (iy < p.H) & (ix < p.W);
-        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
-        rg[i] = buf_load4(rdy, off, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < X_LOADS; ++i) {
-        const int pix = pix0 + PR * i;
-        const int py = (pix * 3641) >> 16, px = pix - py * 18;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = swork & (pix < L::XPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
-        rg[DY_LOADS + i] = buf_load4(rx, off, 0);
-      }
-    };
-    auto tile_store = [&](unsigned char* base) {
-#pragma unroll
-      for (int i = 0; i < LOADS; ++i) {
-        u32x2 pc[sp_np(NS)];
-        sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
-        const int pix = (i < DY_LOADS) ? pix0 + PR * i : L::DYPIX + pix0 + PR * (i - DY_LOADS);
-        const int o = pix * S + gq * 8;
-        if (swork && (i < DY_LOADS ? pix < L::DYPIX : pix < L::DYPIX + L::XPIX)) {
-#pragma unroll
-          for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(base + q * PIECE + o) = pc[q];
-        }
-      }
-    };
-    if (t_lo < t_hi) {
-      tile_load(t_lo);
-      tile_store(lds);
-      if (t_lo + 1 < t_hi) tile_load(t_lo + 1);
-    }
-    __syncthreads();                                   // barrier t_lo: the first tile is staged
-    for (int t = t_lo; t < t_hi; ++t) {
-      if (t + 1 < t_hi) {
-        tile_store(lds + ((t + 1 - t_lo) & 1) * BUF);  // (the consumers left this buffer before the last barrier)
-        if (t + 2 < t_hi) tile_load(t + 2);            // in flight for a whole tile of MFMAs
-      }
-      __syncthreads();                                 // barrier t+1
-    }
-    return;
-  }
-
-  // ---------------------------------------------------------------- consumers: wave = kernel row
-  const int kh = wave;
-  const int g = lane >> 4, li = lane & 15;
-  f32x4 acc[3][TNK][TNK];
-#pragma unroll
-  for (int w = 0; w < 3; ++w)
-#pragma unroll
-    for (int n = 0; n < TNK; ++n)
-#pragma unroll
-      for (int k = 0; k < TNK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int lrow = li >> 2, lcol = (li & 3) * 8;
-  const int dy_lane = (4 * g + lrow) * S + lcol;
-  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * S + lcol;
-  for (int t = t_lo; t < t_hi; ++t) {
-    __syncthreads();                                   // barrier t: tile t is staged
-    const unsigned char* img = lds + ((t - t_lo) & 1) * BUF;
-    bf16x8 afr[TNK][sp_np(NS)], bfr[TNK][sp_np(NS)];
-    auto read_a = [&](int ks) {
-#pragma unroll
-      for (int n = 0; n < TNK; ++n)
-#pragma unroll
-        for (int pc = 0; pc < sp_np(NS); ++pc) {
-          const s16x4 v0 = sp_tr_read(img + pc * PIECE + dy_lane + (2 * ks) * 16 * S + n * 32);
-          const s16x4 v1 = sp_tr_read(img + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * S + n * 32);
-          afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-        }
-    };
-    auto read_b = [&](int grp, int k) {
-      const int ks = grp / 3, kw = grp % 3;
-#pragma unroll
-      for (int pc = 0; pc < sp_np(NS); ++pc) {
-        const s16x4 v0 = sp_tr_read(img + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * S + k * 32);
-        const s16x4 v1 = sp_tr_read(img + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * S + k * 32);
-        bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-      }
-    };
-    read_a(0);
-#pragma unroll
-    for (int k = 0; k < TNK; ++k) read_b(0, k);
-#pragma unroll
-    for (int grp = 0; grp < 6; ++grp) {
-      const int kw = grp % 3;
-      if (grp == 3) read_a(1);
-#pragma unroll
-      for (int k = 0; k < TNK; ++k) {
-#pragma unroll
-        for (int pr = 0; pr < sp_nprod(NS); ++pr)
-#pragma unroll
-          for (int n = 0; n < TNK; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (grp + 1 < 6) read_b(grp + 1, k);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  __syncthreads();                                     // the producers' last barrier (t_hi)
-  float* out = p.ws + (size_t)chunk * p.Cout * 9 * p.Cin;
-  const int row9 = 9 * p.Cin;
-  const int obase = ((n0 + 4 * g) * 9 + kh * 3) * p.Cin + k0 + li;
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int n = 0; n < TNK; ++n)
-#pragma unroll
-      for (int k = 0; k < TNK; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
-}
-
 #define WG9_MAXG 8
 struct Wgrad9Group {
   int n;
-  int xcd;                 // 1: blocks are remapped so that each XCD owns a contiguous range of the work list
   int blk_end[WG9_MAXG];
   Wgrad9Args a[WG9_MAXG];
 };
 template <int NS, int TNK>
 __device__ __forceinline__ void wgrad9_sp_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
-  const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bid = (int)blockIdx.x;
   int gi = 0;
   while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
   const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
@@ -2217,192 +2067,6 @@ template <int NS>
 __global__ __launch_bounds__(192) void wgrad9_sp_group_kernel4(Wgrad9Group grp) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9Lds<NS, 4>::BYTES];
   wgrad9_sp_group_entry<NS, 4>(grp, lds);
-}
-
-// ---- wide form of the nine-tap weight gradient (opt-in: hrseg_tune wgrad9_wide=1; MEASURED SLOWER, see conv.hip).  In
-// wgrad9_sp_body a block owns ONE (output tile, input tile) pair and stages its dy tile and x patch alone: a layer of C
-// channels splits and stores every dy / x element C / 48 times, and the staging -- not the MFMAs -- is what the kernel spends
-// its time on (MFMA-busy 0.39).  Here 3 WN WK waves share one staged dy tile of 16 TNK WN output channels and one x patch of
-// 16 TNK WK input channels; wave (kernel row kh, wn, wk) multiplies its own TNK x TNK tile pair out of them.  Instantiated:
-// WN = 2, WK = 1 on 48-channel tiles (96 x 48 block tile, 384 threads, 216 registers, one block per CU): 31 % less staging per
-// MFMA, 8 loads per thread and tile instead of 11.  (2 x 2 waves would halve the staging but twelve waves per CU allow 168
-// registers where the body needs ~240: 93 spilled; the 64-channel tiling has 192 accumulator registers per wave and no wide form.)
-// Tile walk, MFMA order inside a tile and the workspace layout are those of wgrad9_sp_body (same ordered reduce afterwards).
-template <int NS, int TN, int TK, int WN, int WK>
-struct SpWgrad9WideLds {
-  static constexpr int SA = sp_row_stride(16 * TN * WN), SB = sp_row_stride(16 * TK * WK);   // bytes per pixel row: dy tile, x patch
-  static constexpr int DYPIX = 64, XPIX = 6 * 18;
-  static constexpr int PIECE = DYPIX * SA + XPIX * SB;
-  static constexpr int BYTES = sp_np(NS) * PIECE;
-};
-
-template <int NS, int TN, int TK, int WN, int WK>
-__device__ __forceinline__ void wgrad9_wide_body(const Wgrad9Args& p, unsigned char* lds, const int pair, const int chunk) {
-  using L = SpWgrad9WideLds<NS, TN, TK, WN, WK>;
-  constexpr int SA = L::SA, SB = L::SB, PIECE = L::PIECE, XBASE = L::DYPIX * SA;
-  constexpr int NT = 192 * WN * WK;
-  constexpr int GA = 4 * TN * WN, GB = 4 * TK * WK;          // 16-byte granules per pixel: dy tile, x patch
-  static_assert(NT % GA == 0 && NT % GB == 0, "a staging round covers whole pixels");
-  constexpr int PRA = NT / GA, PRB = NT / GB;                  // pixels per round
-  constexpr int DY_LOADS = (L::DYPIX + PRA - 1) / PRA, X_LOADS = (L::XPIX + PRB - 1) / PRB, LOADS = DY_LOADS + X_LOADS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kh = wave % 3, sub = wave / 3, wn = sub / WK, wk = sub - wn * WK;      // kernel row, sub-tile of the block tile
-  const int g = lane >> 4, li = lane & 15;
-  const int nkt = p.Cin / (16 * TK * WK);
-  const int ct = pair / nkt, kt = pair - ct * nkt;
-  const int n0 = ct * 16 * TN * WN, k0 = kt * 16 * TK * WK;
-  const int t_lo = chunk * p.per, t_hi = min(t_lo + p.per, p.ntiles);
-  float dyscale, dyinv;
-  sp_pow2_scale(p.dymax, dyscale, dyinv);
-
-  f32x4 rg[LOADS];
-  const int pixa = tid / GA, gqa = tid - pixa * GA;
-  const int pixb = tid / GB, gqb = tid - pixb * GB;
-  auto tile_load = [&](int t) {
-    const int tx = t % p.tiles_x;
-    int r = t / p.tiles_x;
-    const int ty = r % p.tiles_y, b = r / p.tiles_y;
-    const int y0 = ty * 4, x0 = tx * 16;
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
-#pragma unroll
-    for (int i = 0; i < DY_LOADS; ++i) {
-      const int pix = pixa + PRA * i;
-      const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
-      const bool ok = (pix < L::DYPIX) & (iy < p.H) & (ix < p.W);
-      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gqa)) * 4u : HRSEG_BUF_OOB;
-      rg[i] = buf_load4(rdy, off, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < X_LOADS; ++i) {
-      const int pix = pixb + PRB * i;
-      const int py = (pix * 3641) >> 16, px = pix - py * 18;           // pix / 18
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = (pix < L::XPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gqb)) * 4u : HRSEG_BUF_OOB;
-      rg[DY_LOADS + i] = buf_load4(rx, off, 0);
-    }
-  };
-  auto tile_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      u32x2 pc[sp_np(NS)];
-      sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
-      const int pix = (i < DY_LOADS) ? pixa + PRA * i : pixb + PRB * (i - DY_LOADS);
-      const int o = (i < DY_LOADS) ? pix * SA + gqa * 8 : XBASE + pix * SB + gqb * 8;
-      if (i < DY_LOADS ? pix < L::DYPIX : pix < L::XPIX) {
-#pragma unroll
-        for (int q = 0; q < sp_np(NS); ++q) *reinterpret_cast<u32x2*>(lds + q * PIECE + o) = pc[q];
-      }
-    }
-  };
-
-  f32x4 acc[3][TN][TK];
-#pragma unroll
-  for (int w = 0; w < 3; ++w)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k) acc[w][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int lrow = li >> 2, lcol = (li & 3) * 8;
-  const int dy_lane = (4 * g + lrow) * SA + lcol + wn * TN * 32;                       // + (2ks+h)*16*SA + n*32
-  const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * SB + lcol + wk * TK * 32;      // + ((2ks+h)*18 + kw)*SB + k*32
-
-  if (t_lo < t_hi) tile_load(t_lo);
-  for (int t = t_lo; t < t_hi; ++t) {
-    __syncthreads();                         // every wave is done with the previous tile's images
-    tile_store();
-    if (t + 1 < t_hi) tile_load(t + 1);      // in flight behind this tile's MFMAs
-    __syncthreads();
-    bf16x8 afr[TN][sp_np(NS)], bfr[TK][sp_np(NS)];
-    auto read_a = [&](int ks) {
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int pc = 0; pc < sp_np(NS); ++pc) {
-          const s16x4 v0 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks) * 16 * SA + n * 32);
-          const s16x4 v1 = sp_tr_read(lds + pc * PIECE + dy_lane + (2 * ks + 1) * 16 * SA + n * 32);
-          afr[n][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-        }
-    };
-    auto read_b = [&](int grp, int k) {
-      const int ks = grp / 3, kw = grp % 3;
-#pragma unroll
-      for (int pc = 0; pc < sp_np(NS); ++pc) {
-        const s16x4 v0 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks) * 18 + kw) * SB + k * 32);
-        const s16x4 v1 = sp_tr_read(lds + pc * PIECE + x_lane + ((2 * ks + 1) * 18 + kw) * SB + k * 32);
-        bfr[k][pc] = __builtin_bit_cast(bf16x8, (s16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-      }
-    };
-    read_a(0);
-#pragma unroll
-    for (int k = 0; k < TK; ++k) read_b(0, k);
-#pragma unroll
-    for (int grp = 0; grp < 6; ++grp) {
-      const int kw = grp % 3;
-      if (grp == 3) read_a(1);
-#pragma unroll
-      for (int k = 0; k < TK; ++k) {
-#pragma unroll
-        for (int pr = 0; pr < sp_nprod(NS); ++pr)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[kw][n][k] = sp_mma_p<NS>(pr, afr[n], bfr[k], acc[kw][n][k]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (grp + 1 < 6) read_b(grp + 1, k);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-
-  float* out = p.ws + (size_t)chunk * p.Cout * 9 * p.Cin;
-  const int row9 = 9 * p.Cin;
-  const int obase = ((n0 + wn * 16 * TN + 4 * g) * 9 + kh * 3) * p.Cin + k0 + wk * 16 * TK + li;
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int k = 0; k < TK; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          out[obase + (16 * n + e) * row9 + kw * p.Cin + 16 * k] = NS == 4 ? acc[kw][n][k][e] * dyinv : acc[kw][n][k][e];
-}
-
-template <int NS, int TN, int TK, int WN, int WK>
-__global__ __launch_bounds__(192 * WN * WK) void wgrad9_wide_group_kernel(Wgrad9Group grp) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[SpWgrad9WideLds<NS, TN, TK, WN, WK>::BYTES];
-  const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  int gi = 0;
-  while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
-  const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
-  const Wgrad9Args& p = grp.a[gi];
-  const int npairs = (p.Cout / (16 * TN * WN)) * (p.Cin / (16 * TK * WK));
-  wgrad9_wide_body<NS, TN, TK, WN, WK>(p, lds, local % npairs, local / npairs);
-}
-
-// role-split kernels (fp16x2 only): 384 threads = three consumer + three producer waves, two image buffers.
-// Blocks are remapped so that each XCD owns a contiguous range of the work list: the tile pairs of one pixel chunk (which
-// re-read the same dy / x tiles) then share one L2.
-template <int NS, int TNK>
-__device__ __forceinline__ void wgrad9_ws_group_entry(const Wgrad9Group& grp, unsigned char* lds) {
-  const int bid = grp.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  int gi = 0;
-  while (gi + 1 < grp.n && bid >= grp.blk_end[gi]) ++gi;
-  const int local = bid - (gi ? grp.blk_end[gi - 1] : 0);
-  const Wgrad9Args& p = grp.a[gi];
-  const int npairs = (p.Cout / (16 * TNK)) * (p.Cin / (16 * TNK));
-  wgrad9_ws_body<NS, TNK>(p, lds, local % npairs, local / npairs);
-}
-template <int NS>
-__global__ __launch_bounds__(384) void wgrad9_ws_group_kernel3(Wgrad9Group grp) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SpWgrad9Lds<NS, 3>::BYTES];
-  wgrad9_ws_group_entry<NS, 3>(grp, lds);
-}
-template <int NS>
-__global__ __launch_bounds__(384) void wgrad9_ws_group_kernel4(Wgrad9Group grp) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SpWgrad9Lds<NS, 4>::BYTES];
-  wgrad9_ws_group_entry<NS, 4>(grp, lds);
 }
 
 // dW[i] += sum over chunks (in chunk order) of ws[chunk][i]; n4 = elements / 4 per problem

@@ -27,44 +27,14 @@ int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipS
 #undef WGS
   return 1;
 }
-// six-wave forms (fp16x2).  kind 1: two output-channel tiles of 48 per block share one x patch (96 x 48 block tile);
-// kind 2: the 64 x 64 tile pair of the one-pair-per-block kernel, its input channels split over two waves per kernel row
-// (4 x 2 tiles and 96 accumulator registers per wave instead of 4 x 4 and 192)
-int launch_wgrad9_wide(int kind, const Wgrad9Group& g, int nblocks, hipStream_t st) {
-  if (kind == 1) hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 3, 3, 2, 1>), dim3(nblocks), dim3(384), 0, st, g);
-  else if (kind == 2) hipLaunchKernelGGL((wgrad9_wide_group_kernel<4, 4, 2, 1, 2>), dim3(nblocks), dim3(384), 0, st, g);
-  else return HRSEG_ERR_UNSUPPORTED;
-  HRSEG_LAUNCH_CHECK("wgrad9_wide");
-  return 0;
-}
-int launch_wgrad9_reduce(const Wgrad9Reduce& r, int rblocks, hipStream_t st) {
-  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
-  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
-  return 0;
-}
-int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st, int ws) {
-  // role-split form (three consumer + three producer waves).  48-channel tiles: 162 registers, two blocks per CU.  The
-  // 64-channel tiling keeps 192 accumulator registers per consumer wave: with six waves per block that spills (a block of
-  // six waves caps a wave at 256 registers), so it stays on the block-synchronous kernel unless wgrad9_ws = 2 forces it.
-  if (ns == 4 && ((ws && tnk == 3) || ws == 2)) {
-    if (tnk == 3) hipLaunchKernelGGL((wgrad9_ws_group_kernel3<4>), dim3(nblocks), dim3(384), 0, st, g);
-    else hipLaunchKernelGGL((wgrad9_ws_group_kernel4<4>), dim3(nblocks), dim3(384), 0, st, g);
-    HRSEG_LAUNCH_CHECK("wgrad9_ws");
-    if (rblocks > 0) {
-      hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
-      HRSEG_LAUNCH_CHECK("wgrad9_reduce");
-    }
-    return 0;
-  }
+int launch_wgrad9_kernels(int ns, int tnk, const Wgrad9Group& g, int nblocks, const Wgrad9Reduce& r, int rblocks, hipStream_t st) {
 #define W9(NS_) if (ns == NS_) { \
     if (tnk == 3) hipLaunchKernelGGL((wgrad9_sp_group_kernel3<NS_>), dim3(nblocks), dim3(192), 0, st, g); \
     else hipLaunchKernelGGL((wgrad9_sp_group_kernel4<NS_>), dim3(nblocks), dim3(192), 0, st, g); }
   W9(1) W9(2) W9(3) W9(4)
 #undef W9
   HRSEG_LAUNCH_CHECK("wgrad9");
-  if (rblocks > 0) {                      // (0: the caller reduces later, after the wide-form launch of the same call)
-    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
-    HRSEG_LAUNCH_CHECK("wgrad9_reduce");
-  }
+  hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(rblocks), dim3(256), 0, st, r);
+  HRSEG_LAUNCH_CHECK("wgrad9_reduce");
   return 0;
 }

@@ -30,7 +30,6 @@ _SIDE = {}
 
 
 _SIDE_ENABLED = None
-_WGRAD_ORDER = os.environ.get("HRSEG_WGRAD_ORDER", "before")
 _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the backward of residual layers reads z for its ReLU mask
 
 
@@ -290,10 +289,8 @@ class Recorder:
                                dbeta=bn.bias._hr_gstore, dres=dres, dres_accumulate=dres_acc, nseg=self.bn_segments,
                                dy_absmax=gmaxs[i]))
             dys = ops.bn_bwd_group(bw, eval_mode, sync=self.sync)
-            # order of the two gradients (HRSEG_WGRAD_ORDER): "after" = the weight gradient is issued on the side stream BEHIND
-            # the data gradient of the same layer, so that it runs beside the BatchNorm backward of the NEXT (earlier) layer --
-            # an MFMA-bound kernel next to bandwidth-bound ones -- instead of beside its own data gradient (two MFMA-bound
-            # kernels sharing the CUs gain nothing); "before" = round-2 order
+            # the weight gradient is issued on the side stream BEFORE the data gradient of the same layer (issuing it behind,
+            # so that it would run beside the next BatchNorm backward, measured 55.9 vs 53.8 ms per step)
             def weight_gradients():
                 side = wgrad_stream(dys[0].device)
                 if side is not None:
@@ -317,8 +314,7 @@ class Recorder:
                         for x in xs:
                             x.data.record_stream(side)
                     self.used_side = True
-            if _WGRAD_ORDER != "after":
-                weight_gradients()
+            weight_gradients()
             # data gradients: rounds of problems whose inputs are distinct tensors
             todo = [i for i, x in enumerate(xs) if x.needs_grad]
             while todo:
@@ -343,8 +339,6 @@ class Recorder:
                     for i, o in zip(rnd, got):
                         xs[i].grad = o
                 todo = rest
-            if _WGRAD_ORDER == "after":
-                weight_gradients()
         self._push(bwd)
         return zs
 

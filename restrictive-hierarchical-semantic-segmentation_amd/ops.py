@@ -290,35 +290,9 @@ def _check_sync_bn_shapes(sync, items, device):
     _SYNC_BN_CHECKED.add(sig)
 
 
-_BN_ACC = {}        # (device index, stream) -> zeroed fp64 arena of the fused-finalize BatchNorm launches
-BN_ACC_ROWS = 16    # csrc/bn_elem.hip BN_ACC_R
-
-
-def _bn_acc(device, sizes):
-    """accumulator slices (hrseg_bn_*_t.acc) for the problems of one grouped call: `sizes` doubles each, cut from an arena
-    that is zeroed when it is created -- every call leaves its slices zero, and calls of one stream run in order, so the
-    same arena serves every call of that stream.  Opt-in (HRSEG_BN_FUSED_FINALIZE=1), default None = the three-launch form:
-    measured on the HRNet step the fused form is 0.8 ms SLOWER (54.45 vs 53.63 ms, same box; UNet equal) -- every block of the
-    statistics kernel now ends with a round trip of memory-side fp64 atomics, and the last block finishes the layer alone,
-    which together cost more than the 6 us finalize launch they replace."""
-    if os.environ.get("HRSEG_BN_FUSED_FINALIZE", "0") != "1":
-        return None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    need = sum(sizes)
-    buf = _BN_ACC.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.zeros(max(need, 1 << 17), dtype=torch.float64, device=device)
-        _BN_ACC[key] = buf
-    out, off = [], 0
-    for n in sizes:
-        out.append(buf[off:off + n])
-        off += n
-    return out
-
-
 def bn_fwd_group(items, training, sync=None):
     """items: list of dict(y, gamma, beta, rm, rv, nbt, momentum, eps, residual, relu[, out]);
-    -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply; HRSEG_BN_FUSED_FINALIZE=1: two).
+    -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply).
     sync (a process group, training only): cross-rank batch statistics -- the partial sums of all problems live in one
     buffer that is all-reduced between the statistics and the finalize phase (opt-in synchronised BN)."""
     n = len(items)
@@ -331,13 +305,9 @@ def bn_fwd_group(items, training, sync=None):
         _check_sync_bn_shapes(sync, items, items[0]["y"].device)
         total = sum(_nchunks(_npix(it["y"]), it["y"].shape[3]) * 2 * it["y"].shape[3] for it in items)
         pool = torch.empty(total, dtype=torch.float64, device=items[0]["y"].device)
-    accs = None
-    if training and sync is None:
-        accs = _bn_acc(items[0]["y"].device, [BN_ACC_ROWS * 2 * it["y"].shape[3] + 1 for it in items])
     for i, (a, it) in enumerate(zip(arr, items)):
         y = it["y"]
         Cn, npix = y.shape[3], _npix(y)
-        a.acc = ptr(accs[i]) if accs is not None else None
         z = it.get("out")
         if z is None:
             z = torch.empty(y.shape, dtype=torch.float32, device=y.device)
@@ -378,7 +348,7 @@ def bn_fwd_group(items, training, sync=None):
 
 def bn_bwd_group(items, eval_mode, sync=None):
     """items: list of dict(dz, z, relu, y, coef, dgamma, dbeta, dres, dres_accumulate); dy is written
-    in place over dz.  Three launches for the whole list (HRSEG_BN_FUSED_FINALIZE=1: two).  sync: see bn_fwd_group (the backward's batch means become
+    in place over dz.  Three launches for the whole list.  sync: see bn_fwd_group (the backward's batch means become
     global; dgamma / dbeta receive this rank's share, so the gradient all-reduce sums them to the global value)."""
     n = len(items)
     arr = (_lib.BnBwd * n)()
@@ -394,14 +364,9 @@ def bn_bwd_group(items, eval_mode, sync=None):
             nch = max(nseg, nch // nseg * nseg) if nseg > 1 else nch
             total += (nch + nseg) * 2 * Cn
         pool = zeros((total,), torch.float64, items[0]["y"].device)
-    accs = None
-    if sync is None:
-        accs = _bn_acc(items[0]["y"].device,
-                       [BN_ACC_ROWS * max(1, int(it.get("nseg", 1))) * 2 * it["y"].shape[3] + 1 for it in items])
     for i, (a, it) in enumerate(zip(arr, items)):
         y, dz, z = it["y"], it["dz"], it["z"]
         Cn, npix = y.shape[3], _npix(y)
-        a.acc = ptr(accs[i]) if accs is not None else None
         nseg = int(it.get("nseg", 1))
         nch = _nchunks(npix, Cn)
         if nseg > 1:                                  # chunks never straddle two segments

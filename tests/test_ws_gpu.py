@@ -299,98 +299,32 @@ def test_fp16x2_out_of_range_activations_are_loud_and_guarded():
         _lib.set_deterministic(False)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4])
-def test_role_split_wgrad9_bit_identical_to_block_synchronous(n):
-    """the role-split nine-tap weight gradient (three consumer + three producer waves, two image buffers, one barrier per
-    tile) adds the same products in the same order as the block-synchronous body: identical bits, for one problem and for
-    the grouped branch launches, including ragged image edges and accumulation into an existing gradient"""
+@pytest.mark.parametrize("cfg", ["branches1", "branches3", "branches4", "tiles64"])
+def test_nine_tap_weight_gradient_matches_torch_and_is_bit_reproducible(cfg):
+    """the nine-tap weight gradient (per-block partial sums in a workspace + ordered reduce, no atomics) on the grouped branch
+    launches (48-channel tiling) and on 64-channel tilings (UNet, the HRNet stem stage): ragged image edges, accumulation into
+    an existing gradient, two runs give the same bits, values against torch"""
     from hrseg_amd import _lib, ops
     pr = _lib.CONV_PRECISION["fp16x2"]
-    g = torch.Generator().manual_seed(40 + n)
-    chans, sizes = [48, 96, 192, 384][:n], [(61, 83), (31, 42), (16, 21), (8, 11)][:n]
-    xs = [torch.randn(5, h, w, c, generator=g).cuda() for c, (h, w) in zip(chans, sizes)]
-    dys = [(torch.randn(5, h, w, c, generator=g) * 1e-3).cuda() for c, (h, w) in zip(chans, sizes)]
+    g = torch.Generator().manual_seed(40 + len(cfg))
+    if cfg == "tiles64":
+        shapes = [(64, 128, 37, 45, 3), (128, 64, 18, 23, 3), (256, 256, 9, 12, 3)]
+    else:
+        n = int(cfg[-1])
+        shapes = [(c, c, h, w, 5) for c, (h, w) in zip([48, 96, 192, 384][:n], [(61, 83), (31, 42), (16, 21), (8, 11)][:n])]
+    xs = [torch.randn(b, h, w, ci, generator=g).cuda() for ci, co, h, w, b in shapes]
+    dys = [(torch.randn(b, h, w, co, generator=g) * 1e-3).cuda() for ci, co, h, w, b in shapes]
     gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
-    base = [torch.randn(c, 9, c, generator=g).cuda() for c in chans]
+    base = [torch.randn(co, 9, ci, generator=g).cuda() for ci, co, h, w, b in shapes]
     outs = []
-    try:
-        for ws in (1, 0):
-            _lib.tune(wgrad9_ws=ws)
-            dws = [b.clone() for b in base]
-            _lib.launch_count(None, reset=True)
-            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
-            assert _lib.launch_count("wgrad9") == 1
-            outs.append(dws)
-    finally:
-        _lib.tune(wgrad9_ws=0)
-    for a, b, x, dy, b0, c in zip(outs[0], outs[1], xs, dys, base, chans):
-        assert torch.equal(a, b), "role-split and block-synchronous weight gradients differ"
-        xr = x.permute(0, 3, 1, 2).cpu().requires_grad_(False)
-        wr = torch.zeros(c, c, 3, 3, requires_grad=True)
-        F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
-        got = (a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu()
-        assert _rel(got, wr.grad) < 4e-5
-
-
-@pytest.mark.parametrize("n", [1, 2, 4])
-def test_wide_wgrad9_matches_the_one_pair_per_block_kernels(n):
-    """the wide nine-tap weight gradient (opt-in, hrseg_tune wgrad9_wide=1: two 48-channel output tiles of a block share one
-    staged x patch; the 96-channel and wider branches) against the one-pair-per-block kernels and torch; ragged image edges, accumulation into an existing
-    gradient, the 48-channel branch staying on the narrow kernel in the same call; bit-reproducible (ordered reduce)"""
-    from hrseg_amd import _lib, ops
-    pr = _lib.CONV_PRECISION["fp16x2"]
-    g = torch.Generator().manual_seed(50 + n)
-    chans, sizes = [96, 48, 192, 384][:n], [(31, 42), (61, 83), (16, 21), (8, 11)][:n]
-    xs = [torch.randn(5, h, w, c, generator=g).cuda() for c, (h, w) in zip(chans, sizes)]
-    dys = [(torch.randn(5, h, w, c, generator=g) * 1e-3).cuda() for c, (h, w) in zip(chans, sizes)]
-    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
-    base = [torch.randn(c, 9, c, generator=g).cuda() for c in chans]
-    outs = {}
-    try:
-        for wide in (1, 0, 11):
-            _lib.tune(wgrad9_wide=wide % 10)
-            dws = [b.clone() for b in base]
-            _lib.launch_count(None, reset=True)
-            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
-            assert _lib.launch_count("wgrad9") == 1 and _lib.launch_count("wgrad9_wide") == (1 if wide else 0)
-            outs[wide] = dws
-    finally:
-        _lib.tune(wgrad9_wide=0)             # (the default: the wide form measured slower on the branch groups)
-    for a, a2, b, x, dy, b0, c in zip(outs[1], outs[11], outs[0], xs, dys, base, chans):
-        assert torch.equal(a, a2), "two runs of the wide form differ"
-        assert _rel(a - b0, b - b0) < 2e-5
-        xr = x.permute(0, 3, 1, 2).cpu()
-        wr = torch.zeros(c, c, 3, 3, requires_grad=True)
-        F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
-        assert _rel((a - b0).view(c, 3, 3, c).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
-
-
-@pytest.mark.parametrize("n", [1, 3])
-def test_six_wave_form_of_the_64_channel_wgrad9_bit_identical_to_the_three_wave_kernel(n):
-    """64-channel tilings (UNet, the HRNet stem stage): the six-wave form (opt-in, hrseg_tune wgrad9_split4=1) splits every kernel row's 4 x 4 tiles over two waves;
-    tile walk, pixel chunks, per-accumulator product order and the ordered reduce are those of wgrad9_sp_group_kernel4, so the
-    gradients must be IDENTICAL bit for bit (hrseg_tune wgrad9_split4=0 runs the three-wave kernel)"""
-    from hrseg_amd import _lib, ops
-    pr = _lib.CONV_PRECISION["fp16x2"]
-    g = torch.Generator().manual_seed(60 + n)
-    cfg = [(64, 128, 37, 45), (128, 64, 18, 23), (256, 256, 9, 12)][:n]
-    xs = [torch.randn(3, h, w, ci, generator=g).cuda() for ci, co, h, w in cfg]
-    dys = [(torch.randn(3, h, w, co, generator=g) * 1e-3).cuda() for ci, co, h, w in cfg]
-    gms = [d.abs().max().reshape(1).repeat(64) for d in dys]
-    base = [torch.randn(co, 9, ci, generator=g).cuda() for ci, co, h, w in cfg]
-    outs = {}
-    try:
-        for split in (1, 0):
-            _lib.tune(wgrad9_split4=split)
-            dws = [b.clone() for b in base]
-            _lib.launch_count(None, reset=True)
-            ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
-            assert _lib.launch_count("wgrad9") == 1 and _lib.launch_count("wgrad9_wide") == split
-            outs[split] = dws
-    finally:
-        _lib.tune(wgrad9_split4=0)           # (the default: measured slower on the UNet step)
-    for a, b, x, dy, b0, (ci, co, h, w) in zip(outs[1], outs[0], xs, dys, base, cfg):
-        assert torch.equal(a, b), "six-wave and three-wave weight gradients differ"
+    for _ in range(2):
+        dws = [b.clone() for b in base]
+        _lib.launch_count(None, reset=True)
+        ops.conv_wgrad_group(xs, dys, dws, 3, 1, prec=pr, gmaxs=gms)
+        assert _lib.launch_count("wgrad9") == 1
+        outs.append(dws)
+    for a, a2, x, dy, b0, (ci, co, h, w, b) in zip(outs[0], outs[1], xs, dys, base, shapes):
+        assert torch.equal(a, a2), "two runs of the nine-tap weight gradient differ"
         wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
         F.conv2d(x.permute(0, 3, 1, 2).cpu(), wr, padding=1).backward(dy.permute(0, 3, 1, 2).cpu())
         assert _rel((a - b0).view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
