@@ -372,24 +372,16 @@ def self_launch(args):
     return proc.returncode if proc.returncode != 0 or lines else 1
 
 
-def comm_only(args, model, sync, rank, world, device):
+def measure_exchange(args, model, sync, world, device):
     """the gradient exchange of one step in isolation: the buckets GradSync issues during the last backward level
-    (same boundaries, same side stream, same backend), on a gradient buffer of the model's size, nothing else running.
-    One JSON line from rank 0: ms per exchange, algorithm bandwidth (bytes / time) and ring bus bandwidth
-    (2 (N-1)/N x that), so that a scaling run can tell compute from exchange (reference: train.py:509-510)."""
+    (same boundaries, same side stream, same backend), on the model's own gradient buffer, nothing else running.
+    -> dict(ms per exchange, bytes, buckets, algorithm / ring bus bandwidth, backend); every rank must call it
+    (reference analogue: train.py:509-510, nn.DataParallel's reduce-add)."""
     import torch.distributed as dist
-    from hrseg_amd.parallel import GradSync, bucket_offsets
+    from hrseg_amd.parallel import bucket_offsets
     flat = model.flatten_parameters(device)
-    if sync is None:
-        os.environ["HRSEG_FORCE_SYNC"] = "1"
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29534")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-        sync = GradSync(model)
     offs = bucket_offsets(flat, sync.marks)
     marks = sorted(offs, key=lambda m: -offs[m])          # the order the reverse pass crosses them
-    flat.grad.normal_()
 
     def exchange():
         for m in marks:
@@ -411,17 +403,36 @@ def comm_only(args, model, sync, rank, world, device):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    if rank == 0:
-        nbytes = flat.numel * 4
-        ms = 1e3 * dt / args.steps
-        algbw = nbytes / (dt / args.steps) / 1e9
-        print(json.dumps({
-            "metric": "gradient exchange per step (bucketed all-reduce of the flat fp32 gradient)", "value": round(ms, 3),
-            "unit": "ms", "higher_is_better": False, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "bytes": nbytes, "buckets": [[lo, hi] for lo, hi in sync.launched], "algbw_GBps": round(algbw, 1),
+    nbytes = flat.numel * 4
+    algbw = nbytes / (dt / args.steps) / 1e9
+    return {"ms": round(1e3 * dt / args.steps, 3), "bytes": nbytes, "buckets_bytes": [4 * (hi - lo) for lo, hi in sync.launched],
+            "algbw_GBps": round(algbw, 1),
             "busbw_GBps": round(algbw * 2 * (world - 1) / max(world, 1), 1) if world > 1 else None,
             "backend": sync.backend + ":" + (dist.get_backend() if dist.is_initialized() else "-"),
-            "note": "exchange only, no compute beside it; in a train step it overlaps pass 0 of the backward"}), flush=True)
+            "note": "exchange only, no compute beside it; in a train step it overlaps pass 0 of the backward"}
+
+
+def comm_only(args, model, sync, rank, world, device):
+    """`--comm-only`: ONE JSON line from rank 0 with the exchange alone (measure_exchange), so that a scaling run can tell
+    compute from exchange"""
+    import torch.distributed as dist
+    from hrseg_amd.parallel import GradSync
+    flat = model.flatten_parameters(device)
+    if sync is None:
+        os.environ["HRSEG_FORCE_SYNC"] = "1"
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        sync = GradSync(model)
+    flat.grad.normal_()
+    r = measure_exchange(args, model, sync, world, device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "gradient exchange per step (bucketed all-reduce of the flat fp32 gradient)", "value": r["ms"],
+            "unit": "ms", "higher_is_better": False, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "bytes": r["bytes"], "buckets": [[lo, hi] for lo, hi in sync.launched], "algbw_GBps": r["algbw_GBps"],
+            "busbw_GBps": r["busbw_GBps"], "backend": r["backend"], "note": r["note"]}), flush=True)
 
 
 def main():
@@ -555,6 +566,22 @@ def main():
     dt_async, _ = timed(step_async, args.steps)
     host_ms, launches = host_issue()
     log("host issue %.1f ms per step (%s); conv launches per step %s" % (host_ms, launch_mode(), launches))
+    exchange = None
+    if sync is not None:
+        # what a scaling run needs to be read: the exchange alone (same job, same buckets), each bucket's overlap with the
+        # reverse pass (events), and the slowest rank's host issue time
+        sync.timing = True
+        step()
+        step()
+        buckets = sync.bucket_report()
+        sync.timing = False
+        hmax = torch.tensor([host_ms], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        exchange = measure_exchange(args, model, sync, world, device)
+        exchange.update(buckets_in_step=buckets, host_issue_ms_slowest_rank=round(float(hmax), 2),
+                        exposed_ms_in_step=round(sum(b.get("exposed_ms") or 0.0 for b in buckets), 3))
+        log("exchange alone %.2f ms; in the step: %s" % (exchange["ms"], json.dumps(buckets)))
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         gf = TRAIN_GFLOP_PER_IMAGE.get((args.model, hier))
@@ -575,7 +602,10 @@ def main():
                        "launch": launch_mode(),
                        "conv_arithmetic": CONV_ARITHMETIC.get(conv_dtype, conv_dtype),
                        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
-                       "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
+                       "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "comm": (None if sync is None else
+                                "hrseg_comm_* (the library's own RCCL wrappers, HRSEG_COMM=rccl)" if sync.backend == "rccl" else
+                                "torch.distributed all_reduce (HRSEG_COMM=torch, default)")},
             "batch_body_from_host": {"value": round(world * args.batch * args.steps / dt_host, 3), "unit": "images/s",
                                      "ms_per_step": round(1e3 * dt_host / args.steps, 2),
                                      "note": "same body with the batch copied from pinned host memory inside the timed "
@@ -583,6 +613,8 @@ def main():
             "ms_per_step_no_readback": round(1e3 * dt_async / args.steps, 2),
             "host_issue_ms": host_ms, "conv_launches_per_step": launches,
         }
+        if exchange is not None:
+            line["gradient_exchange"] = exchange
         if gf is not None and args.size == 620:
             tf = ips * gf / 1e3
             line["step_conv_roofline"] = {"train_gflop_per_image": gf, "achieved_tflops": round(tf, 2),

@@ -686,7 +686,8 @@ class HighResolutionModule(nn.Module):
         xs = list(xs)
         for kblk in range(depth):
             blks = [self.branches[b][kblk] for b in range(nb)]
-            ys = rec.conv_bn_group([(xs[b], blks[b].conv1, blks[b].bn1, None) for b in range(nb)], relu=True)
+            ys = rec.conv_bn_group([(xs[b], blks[b].conv1, blks[b].bn1, None) for b in range(nb)], relu=True,
+                                   single_reader=True)
             xs = rec.conv_bn_group([(ys[b], blks[b].conv2, blks[b].bn2, xs[b]) for b in range(nb)], relu=True)
         return xs
 

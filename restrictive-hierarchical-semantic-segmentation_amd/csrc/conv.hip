@@ -308,7 +308,17 @@ static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   launch_weight_images(g, end, st);
   return true;
 }
+static int g_ws_epi_early = 1;          // hrseg_tune "ws_epi_early": 0 = the wave-specialised body reads accumulate / residual values at the tile's end
+// hrseg_tune "ws_epi_cost" / "ws_epi_acc_cost": what a tile costs beyond its slabs, in slab times (0 = the defaults below,
+// negative = none), for the block partition of a grouped launch.  A tile's prologue / epilogue (tile switch, 12 KB of stores per
+// consumer wave, the reads of an accumulating or residual epilogue) is worth about ten slabs: a 48-channel layer's tile is ONE
+// K stage of 14 slabs, so a partition by slab count alone starves it of blocks.  Measured in isolation (tools/ws_epilogue_ab.py,
+// B = 8): four-branch forward 150 -> 121 us, three-branch 112 -> 91, two-branch 75.5 -> 67; accumulating data gradient
+// 171 -> 126 / 127 -> 96 / 85 -> 75 us.  Results do not depend on the partition (no atomics, fixed per-tile order).
+static int g_ws_epi_cost = 0, g_ws_epi_acc_cost = 0;
+static const int WS_EPI_COST = 10, WS_EPI_ACC_COST = 16;
 static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st, int ns = 4) {
+  a.epi_early = g_ws_epi_early;
   ws_set_canvas(a, kind);
   const int ntotal = (int)ws_tiles(a, kind);
   if (!ws_make_images(&a, &kind, 1, st, ns)) return 1;
@@ -333,7 +343,11 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     const int cs = WS_CS[kinds[i]];
     ws_set_canvas(a[i], kinds[i]);
     ntot[i] = ws_tiles(a[i], kinds[i]);
-    cost[i] = (long)(a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
+    a[i].epi_early = g_ws_epi_early;
+    // slabs per tile, plus the tile's epilogue in slab times (an accumulating / residual epilogue waits for its reads)
+    const int ec = g_ws_epi_cost ? (g_ws_epi_cost > 0 ? g_ws_epi_cost : 0) : WS_EPI_COST;
+    const int eac = g_ws_epi_acc_cost ? (g_ws_epi_acc_cost > 0 ? g_ws_epi_acc_cost : 0) : WS_EPI_ACC_COST;
+    cost[i] = (long)(a[i].K / (16 * cs)) * ((9 * cs + 1) / 2) + ((a[i].accumulate || a[i].res) ? eac : ec);
     total += ntot[i] * cost[i];
   }
   int used = 0;
@@ -1251,7 +1265,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"ws_epi_early", &g_ws_epi_early}, {"ws_epi_cost", &g_ws_epi_cost}, {"ws_epi_acc_cost", &g_ws_epi_acc_cost}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

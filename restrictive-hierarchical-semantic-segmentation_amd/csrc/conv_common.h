@@ -33,6 +33,7 @@ struct IgemmArgs {
   unsigned cv_magic;         //   ceil(2^32 / cv_w1): canvas column -> image by multiply-high
   const float* res;          // fused epilogue (inference, BatchNorm folded into w / bias): y = relu?(conv + bias + res[pixel][channel])
   int ldr, relu;             //   res may be null; both are ignored by split-K launches (the planners keep ksplit = 1 when set)
+  int epi_early;             // wave-specialised body: issue the epilogue's reads (accumulate / residual) ahead of the tile's last slab
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for

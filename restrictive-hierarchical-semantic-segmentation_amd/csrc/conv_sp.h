@@ -1570,16 +1570,24 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
         for (int m = 0; m < RPW; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto store_tile = [&](const Geom& q) {
-      // every read of the tile (bias, the values an accumulating launch adds to) is issued before the first store: for
-      // all the compiler knows a store may alias the next read, and a read behind every store is a memory round trip each
-      // (measured on the accumulating data-gradient launches of the step: 156 -> 140 us on average)
+    // Epilogue in two parts.  fetch_add: everything the tile's output ADDS to its accumulators -- bias, the values an
+    // accumulating launch (data gradient into an existing gradient) adds to, the fused residual -- read into registers;
+    // store_acc: scale, add, ReLU, store.  Every read is issued before the first store (for all the compiler knows a store
+    // may alias the next read, and a read behind every store is a memory round trip each: 156 -> 140 us on the accumulating
+    // data-gradient launches).  Tilings with registers to spare inside the grouped kernel's allocation (PF: 48- and 64-channel
+    // tiles on 8 rows, 158 / 178 of the 246 registers the 96-channel tiling makes the kernel allocate anyway) issue fetch_add
+    // S_PF slabs BEFORE the tile's last slab: a 48-channel layer has ONE K stage of 14 slabs (3.5 us) per tile, and reading
+    // the accumulate values at the very end exposed a memory round trip per tile (+23 us per accumulating launch).  Same
+    // arithmetic, same order: bit-identical results.
+    constexpr bool PF = WTN * RPW <= 8;
+    constexpr int S_PF = NSLAB > 10 ? NSLAB - 10 : 0;
+    f32x4 add[RPW][WTN];
+    auto fetch_add = [&](const Geom& q) {
       // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image
       const int cxo = q.x0 + r16;
       const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
       const int ox = cxo - obc * cv_w1, ob = q.b + obc;
       const bool ook = (ox < W) & (obc < cv_nb);
-      f32x4 add[RPW][WTN];
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1607,6 +1615,12 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(rrow + q.nt * BN + 16 * n + 4 * g);
         }
       }
+    };
+    auto store_acc = [&](const Geom& q) {
+      const int cxo = q.x0 + r16;
+      const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
+      const int ox = cxo - obc * cv_w1, ob = q.b + obc;
+      const bool ook = (ox < W) & (obc < cv_nb);
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m;
@@ -1665,8 +1679,19 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
               }
             }
           }
-          if (s == NSLAB - 1 && last_ks) { store_tile(cur); zero_acc(); }
-          __syncthreads();
+          if (PF && s == S_PF && last_ks && p.epi_early) fetch_add(cur);
+          if (s == NSLAB - 1 && last_ks) {
+            if (!(PF && p.epi_early)) fetch_add(cur);
+            store_acc(cur);
+            zero_acc();
+          }
+          // The slab barrier orders LDS traffic only (the producers' ds_writes against these reads).  __syncthreads() would
+          // also wait for every outstanding vector-memory operation of this wave (its workgroup-scope fence emits vmcnt(0)):
+          // the tile's stores after store_acc -- a memory round trip per tile before the next tile's first slab -- and the
+          // loads of fetch_add issued S_PF slabs early.  Nothing another wave of the block reads depends on them, so the
+          // consumers wait for their LDS operations and meet the barrier directly.
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
           wb = wb1;
         }
         pb ^= 1;
@@ -1674,7 +1699,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
       if (!have_next) break;
     }
-    for (int k = total; k & (D - 1); ++k) __syncthreads();      // the producers' loop is unrolled by D slabs
+    for (int k = total; k & (D - 1); ++k) __builtin_amdgcn_s_barrier();      // the producers' loop is unrolled by D slabs
   } else {
     // Producers run a flat loop over the block's slabs (j = 0 .. total-1, indices runtime and wave-uniform): at slab j
     // they store weight slab j+2 (loaded four slabs earlier into register set (j+2)%4) and issue the loads of slab

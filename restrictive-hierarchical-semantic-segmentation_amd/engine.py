@@ -31,6 +31,12 @@ _SIDE = {}
 
 _SIDE_ENABLED = None
 _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the backward of residual layers reads z for its ReLU mask
+# MEASUREMENT ONLY (results are WRONG on purpose; tools/bn_fusion_bound.sh): upper bounds of what a conv <-> BatchNorm fusion
+# could save, measured by leaving the launches out of the real step instead of estimating them on paper --
+#   skip_apply1: no BN-apply launch for tensors with a single convolution reader (conv1 -> conv2 of a BasicBlock): the reader
+#                takes the raw conv output (same bytes, same kernels) = the ceiling of "BN-apply + ReLU in the consumer's staging"
+#   skip_stats:  no BN-statistics launch in the forward = the ceiling of "statistics in the convolution epilogue"
+_EXPERIMENT = set(filter(None, os.environ.get("HRSEG_EXPERIMENT", "").split(",")))
 
 
 def wgrad_stream(device):
@@ -213,7 +219,7 @@ class Recorder:
     def conv_bn(self, x, conv, bn, relu, residual=None, out=None):
         return self.conv_bn_group([(x, conv, bn, residual)], relu, outs=[out])[0]
 
-    def conv_bn_group(self, items, relu, outs=None):
+    def conv_bn_group(self, items, relu, outs=None, single_reader=False):
         """items: list of (x, conv, bn, residual-or-None), independent of each other (the parallel
         HRNet branches, the fuse paths of a module; a single layer is a group of one); relu: one flag or
         one per item.  Per group: one conv launch, three BN launches; backward: three BN launches, one
@@ -258,7 +264,17 @@ class Recorder:
                          stat_div=self.bn_segments, relu_mask=masks[i],
                          out=outs[i] if outs is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
-        zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync)
+        if _EXPERIMENT and self.training and self.sync is None:
+            phases = 7
+            if "skip_apply1" in _EXPERIMENT and single_reader:
+                phases &= ~4
+            if "skip_stats" in _EXPERIMENT:
+                phases &= ~1
+            zc = ops.bn_fwd_group(bn_items, self.training, phases=phases)
+            if not phases & 4:
+                zc = [(y, c) for y, (_, c) in zip(ys, zc)]
+        else:
+            zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync)
         zs = [Act(z) for z, _ in zc]
         if not self.record:
             return zs

@@ -290,7 +290,7 @@ def _check_sync_bn_shapes(sync, items, device):
     _SYNC_BN_CHECKED.add(sig)
 
 
-def bn_fwd_group(items, training, sync=None):
+def bn_fwd_group(items, training, sync=None, phases=7):
     """items: list of dict(y, gamma, beta, rm, rv, nbt, momentum, eps, residual, relu[, out]);
     -> [(z, coef)] with three launches for the whole list (statistics, finalize, apply).
     sync (a process group, training only): cross-rank batch statistics -- the partial sums of all problems live in one
@@ -341,6 +341,8 @@ def bn_fwd_group(items, training, sync=None):
         call("hrseg_bn_fwd_group_phases", n, arr, 1, 1)
         dist.all_reduce(pool, op=dist.ReduceOp.SUM, group=sync)
         call("hrseg_bn_fwd_group_phases", n, arr, 1, 6)
+    elif phases != 7:           # (measurement switches of engine.py only)
+        call("hrseg_bn_fwd_group_phases", n, arr, int(training), int(phases))
     else:
         call("hrseg_bn_fwd_group", n, arr, int(training))
     return [(z, coef) for z, coef, _ in outs]

@@ -103,6 +103,11 @@ class GradSync:
         self._boundary = None
         self._offsets = None
         self.launched = []          # [(lo, hi)] of the last step, for tests/inspection
+        # timing = True: every bucket of a step is bracketed by events on the exchange stream and the end of the reverse pass
+        # is marked on the compute stream; `bucket_report()` then says, per bucket, when it started, how long it took and how
+        # much of it ran AFTER the reverse pass had finished (= not overlapped).  Off in production (events cost host time).
+        self.timing = False
+        self._events = []
         model._grad_hook = self
         if self.world > 1:
             self.broadcast_state()
@@ -141,7 +146,11 @@ class GradSync:
         if self._boundary is None:
             self._boundary = flat.numel
             self.launched = []
+            self._events = []
         if mark == "end":
+            if self.timing and flat.grad.is_cuda:
+                self._bwd_end = torch.cuda.Event(enable_timing=True)
+                self._bwd_end.record()                      # compute stream: the reverse pass (and the weight-gradient join) is done
             self._launch(flat, 0, self._boundary)
             self._finish()
             self._boundary = None
@@ -167,11 +176,22 @@ class GradSync:
             side = wgrad_stream(chunk.device)
             if side is not None:                 # the bucket's weight gradients come from the side stream
                 self._comm_stream.wait_stream(side)
+            ev = None
+            if self.timing:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), lo, hi)
+                ev[0].record(self._comm_stream)
+                self._events.append(ev)
             if self.backend == "rccl":
                 self.comm.all_reduce_(chunk, self._comm_stream)
+                if ev is not None:
+                    ev[1].record(self._comm_stream)
                 return
             with torch.cuda.stream(self._comm_stream):
-                self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if ev is not None:
+                    h.wait()                                # exchange stream waits for the collective's own stream
+                    ev[1].record(self._comm_stream)
+                self._handles.append(h)
         else:
             self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -184,6 +204,28 @@ class GradSync:
                 self.comm.wait(self._comm_stream, torch.cuda.current_stream())
             else:
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+
+def _bucket_report(self):
+    """after a synchronised step with timing on: [{bytes, start_ms (after the first bucket's start), ms, exposed_ms}] --
+    exposed = the part of the bucket's interval that lies behind the end of the reverse pass"""
+    if not self._events:
+        return []
+    torch.cuda.synchronize()
+    t0 = self._events[0][0]
+    end_bwd = t0.elapsed_time(self._bwd_end) if getattr(self, "_bwd_end", None) is not None else None
+    out = []
+    for a, b, lo, hi in self._events:
+        start, stop = t0.elapsed_time(a), t0.elapsed_time(b)
+        exposed = None if end_bwd is None else max(0.0, stop - max(start, end_bwd))
+        out.append({"bytes": 4 * (hi - lo), "start_ms": round(start, 3), "ms": round(stop - start, 3),
+                    "exposed_ms": None if exposed is None else round(exposed, 3)})
+    if end_bwd is not None:
+        out.append({"reverse_pass_end_ms": round(end_bwd, 3)})
+    return out
+
+
+GradSync.bucket_report = _bucket_report
 
 
 def all_reduce_confusion(cms, group=None):
