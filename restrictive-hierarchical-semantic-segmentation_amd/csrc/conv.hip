@@ -797,14 +797,16 @@ static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   return 0;
 }
 // `group_n` problems share the launch: two blocks fit a CU, so the launch's blocks should fill whole rounds of 512 --
-// 256 per problem for one, two or four problems, 1024 / 3 for three (measured on the three-branch group: 139 -> 127 us)
+// 256 per problem for one, two or four problems; 160 for three (ONE round of 480 blocks, all resident at once: 104 us
+// against 119 us for two rounds of 1024 / 3 per problem, tools/wgrad9_sweep.py; four problems in one round -- 128 each --
+// measure slower than two rounds, 164 against 157 us)
 static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n) {
   a.B = s.B; a.H = s.Hi; a.W = s.Wi; a.Cin = s.Cin; a.Cout = s.Cout; a.ldx = s.ldx; a.lddy = s.ldy;
   a.tiles_x = ceil_div(s.Wi, 16); a.tiles_y = ceil_div(s.Hi, 4);
   a.ntiles = s.B * a.tiles_x * a.tiles_y;
   const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
-  const int target = g_wg9_blocks ? g_wg9_blocks : (group_n == 3 ? 341 : 256);
-  int chunks = (group_n == 3 && !g_wg9_blocks) ? target / npairs : ceil_div(target, npairs);
+  const int target = g_wg9_blocks ? g_wg9_blocks : (group_n == 3 ? 160 : 256);
+  int chunks = ceil_div(target, npairs);
   if (chunks > a.ntiles) chunks = a.ntiles;
   if (chunks < 1) chunks = 1;
   a.per = ceil_div(a.ntiles, chunks);

@@ -1582,6 +1582,22 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     constexpr bool PF = WTN * RPW <= 8;
     constexpr int S_PF = NSLAB > 10 ? NSLAB - 10 : 0;
     f32x4 add[RPW][WTN];
+    // The epilogue's launch parameters, pinned in scalar registers: `p` lives in the kernel-argument segment, and left alone
+    // the compiler re-loads its fields where they are used -- one s_load + s_waitcnt lgkmcnt(0) round trip per output row of
+    // EVERY tile's epilogue, with the matrix pipe idle (a tile cost ~2 us beyond its slabs; a 48-channel layer's tile is 4.6 us
+    // of slabs).  A value that went through v_readfirstlane cannot be rematerialised from memory.
+    auto pin_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto pin_p = [](const void* ptr) {
+      const unsigned long long a = (unsigned long long)ptr;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+      return (unsigned long long)lo | ((unsigned long long)hi << 32);
+    };
+    float* const e_y = reinterpret_cast<float*>(pin_p(p.y));
+    const float* const e_bias = reinterpret_cast<const float*>(pin_p(p.bias));
+    const float* const e_res = reinterpret_cast<const float*>(pin_p(p.res));
+    const int e_ldy = pin_i(p.ldy), e_ldr = pin_i(p.ldr), e_acc = pin_i(p.accumulate), e_relu = pin_i(p.relu);
+    const int e_early = pin_i(p.epi_early);
     auto fetch_add = [&](const Geom& q) {
       // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image
       const int cxo = q.x0 + r16;
@@ -1591,26 +1607,26 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + q.nt * BN + 16 * n + 4 * g);
+        if (e_bias) bv = *reinterpret_cast<const f32x4*>(e_bias + q.nt * BN + 16 * n + 4 * g);
 #pragma unroll
         for (int m = 0; m < RPW; ++m) add[m][n] = bv;
       }
-      if (p.accumulate) {
+      if (e_acc) {
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
           const int oy = q.y0 + wave * RPW + m;
           if (oy >= H || !ook) continue;
-          const float* yrow = p.y + ((size_t)(ob * H + oy) * W + ox) * p.ldy;
+          const float* yrow = e_y + ((size_t)(ob * H + oy) * W + ox) * e_ldy;
 #pragma unroll
           for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g);
         }
       }
-      if (p.res) {
+      if (e_res) {
 #pragma unroll
         for (int m = 0; m < RPW; ++m) {
           const int oy = q.y0 + wave * RPW + m;
           if (oy >= H || !ook) continue;
-          const float* rrow = p.res + ((size_t)(ob * H + oy) * W + ox) * p.ldr;
+          const float* rrow = e_res + ((size_t)(ob * H + oy) * W + ox) * e_ldr;
 #pragma unroll
           for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(rrow + q.nt * BN + 16 * n + 4 * g);
         }
@@ -1625,11 +1641,11 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m;
         if (oy >= H || !ook) continue;
-        float* yrow = p.y + ((size_t)(ob * H + oy) * W + ox) * p.ldy;
+        float* yrow = e_y + ((size_t)(ob * H + oy) * W + ox) * e_ldy;
 #pragma unroll
         for (int n = 0; n < WTN; ++n) {
           f32x4 v = acc[n][m] * oscale + add[m][n];
-          if (p.relu) {
+          if (e_relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -1679,9 +1695,9 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
               }
             }
           }
-          if (PF && s == S_PF && last_ks && p.epi_early) fetch_add(cur);
+          if (PF && s == S_PF && last_ks && e_early) fetch_add(cur);
           if (s == NSLAB - 1 && last_ks) {
-            if (!(PF && p.epi_early)) fetch_add(cur);
+            if (!(PF && e_early)) fetch_add(cur);
             store_acc(cur);
             zero_acc();
           }
