@@ -87,6 +87,15 @@ typedef struct {
   const float* residual;    /* forward only, fused epilogue for inference with BatchNorm folded into the weights       */
   int ldr, relu;            /* (hrseg_bn_fold): y = relu?(conv(x, w) + bias + residual[pixel*ldr + channel]); residual
                                may be NULL; zero-initialised fields = plain convolution                               */
+  double* stat_partial;     /* forward only, optional: DEVICE buffer of 256 * 2 * Cout doubles.  A kernel that can (the
+                               wave-specialised 3x3 kernels) leaves the BatchNorm partial sums of its OUTPUT there -- row r
+                               = [sum y over the pixels block r produced][sum y^2], per output channel -- the layout
+                               hrseg_bn_fwd_t.partial has with nchunks = *stat_rows: the caller then runs hrseg_bn_fwd_group_
+                               phases without the statistics phase (phases 6).  The rows are complete sums in a fixed order
+                               per block, but the blocks' LDS atomics meet in any order (last bits of the fp64 sums vary): not
+                               offered in deterministic mode                                                              */
+  int* stat_rows;           /* HOST pointer, out (set by the call, synchronously): rows written to stat_partial; 0 = the
+                               kernel that ran produces no statistics (run the statistics phase).  Required with stat_partial */
 } hrseg_conv_shape_t;
 
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */

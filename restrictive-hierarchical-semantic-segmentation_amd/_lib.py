@@ -32,7 +32,7 @@ _f = C.c_float
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
     _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")] + \
-               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i)]
+               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i), ("stat_partial", _p), ("stat_rows", C.POINTER(C.c_int))]
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
@@ -212,7 +212,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 11    # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 12    # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

@@ -325,6 +325,7 @@ static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st, int ns = 4) {
   const int per = ceil_div(ntotal, 256);
   const dim3 grid((unsigned)ceil_div(ntotal, per));
   const int flip = patch_flip(a);
+  if (a.stat_partial) *a.stat_rows = (int)grid.x;           // one row of partial sums per block
   ++g_cnt[CNT_WS];
   g_cnt[CNT_WS_CANVAS] += a.cv_w1 > 0;
   return launch_ws_kernel(a, kind, flip, (int)grid.x, ntotal, st, ns);
@@ -375,6 +376,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   for (int i = 0; i < n; ++i) {
     const int per = ceil_div((int)ntot[i], blocks[i]);
     g.tiles[i] = ceil_div((int)ntot[i], per);      // blocks that have work
+    if (a[i].stat_partial) *a[i].stat_rows = g.tiles[i];
     g.ksplit[i] = (int)ntot[i];
     end += g.tiles[i];
     g.blk_end[i] = end;
@@ -943,6 +945,12 @@ static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const fl
   pack_taps(a, a.T, oy, ox, wt);
   set_sp_scales(a, s->precision, nullptr);
   a.res = s->residual; a.ldr = s->ldr; a.relu = s->relu;
+  // BatchNorm statistics in the epilogue: offered to the launchers only where the caller gave both pointers, the output is the
+  // BatchNorm's input as stored (no fused residual / ReLU) and the run need not be bit-reproducible
+  if (s->stat_partial && s->stat_rows) {
+    *s->stat_rows = 0;
+    if (!hrseg_g_deterministic && !s->residual && !s->relu && s->Cout <= 1024) { a.stat_partial = s->stat_partial; a.stat_rows = s->stat_rows; }
+  }
 }
 
 // stride-1 data gradient as a forward-style gather over dy with the transposed weights

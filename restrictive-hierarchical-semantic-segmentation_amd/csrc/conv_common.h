@@ -34,6 +34,8 @@ struct IgemmArgs {
   const float* res;          // fused epilogue (inference, BatchNorm folded into w / bias): y = relu?(conv + bias + res[pixel][channel])
   int ldr, relu;             //   res may be null; both are ignored by split-K launches (the planners keep ksplit = 1 when set)
   int epi_early;             // wave-specialised body: issue the epilogue's reads (accumulate / residual) ahead of the tile's last slab
+  double* stat_partial;      // wave-specialised body, forward: BatchNorm partial sums of the output, one row [2][N] per block (else null)
+  int* stat_rows;            // HOST pointer: the launcher writes the number of rows (blocks) there; not read by any kernel
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for

@@ -1407,7 +1407,9 @@ void igemm_patch_sp_kernel(IgemmArgs p, int ntotal) {
 template <int NS, int TH, int WTN, int CS>
 struct SpPatchWsLds {
   using P = SpPatchLds<NS, TH, WTN, CS>;
-  static constexpr int BYTES = 2 * P::PATCH + 3 * P::WSTAGE;       // two patch buffers, three weight slabs
+  static constexpr int STAT_MAXN = 1024;                           // BatchNorm statistics in the epilogue: [2][N] fp64 sums per block
+  static constexpr int STAT = 2 * STAT_MAXN * 8;
+  static constexpr int BYTES = 2 * P::PATCH + 3 * P::WSTAGE + STAT;       // two patch buffers, three weight slabs, the sums
   static constexpr int NSLAB = (9 * CS + 1) / 2;
 };
 
@@ -1466,8 +1468,18 @@ __global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g
 }
 #endif
 
+// sum over the 16 lanes of a DPP row, left in lane 15 of the row (row_shr:1,2,4,8, zero fill for lanes shifted in)
+__device__ __forceinline__ float sp_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+
 template <int NS, int TH, int WTN, int CS, int FLIP>
-__device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end) {
+__device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end,
+                                                    const int block_row = 0) {
   static_assert(NS == 4 || NS == 1, "the wave-specialised body: fp16x2 (two pieces, three products) or bf16 (one piece, one product)");
   using L = SpPatchLds<NS, TH, WTN, CS>;
   constexpr int RPW = TH / 4, BN = 16 * WTN, PW = 18, PP = L::PP;
@@ -1485,6 +1497,11 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   static_assert(P_SLABS + D <= NSLAB - 1, "the next K stage's patch is complete one slab before the stage ends");
   unsigned char* lpatch = lds;                             // [2][PATCH]
   unsigned char* lw = lds + 2 * L::PATCH;                  // [3][WSTAGE]
+  // BatchNorm statistics of the OUTPUT in the epilogue (p.stat_partial, training forward): the block keeps [2][N] fp64 sums
+  // (sum y, sum y^2 per output channel over every pixel of its tiles) in LDS and writes them as ONE row of the partial-sum
+  // buffer the BatchNorm finalize kernel reads -- the statistics kernel, its launch boundary and its pass over y (measured:
+  // 2.6 ms of a 51 ms step with every statistics launch left out) disappear for the layers this kernel produces.
+  double* lstat = reinterpret_cast<double*>(lds + 2 * L::PATCH + 3 * L::WSTAGE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool consumer = __builtin_amdgcn_readfirstlane(wave) < 4;      // wave-uniform: a scalar branch
   const int ptid = tid & 255;
@@ -1504,6 +1521,9 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   const int nks = p.K / (16 * CS);
   if (first >= end) return;
   const int total = (end - first) * nks * NSLAB;           // slabs of this block
+  const bool stat = p.stat_partial != nullptr;
+  if (stat)
+    for (int i = tid; i < 2 * p.N; i += 512) lstat[i] = 0.0;            // (ordered before the first epilogue by the prologue barrier)
 
   // tile t -> (channel tile fastest, then tile column, tile row, image); walked incrementally (the divisions
   // happen once per block: a producer wave has no issue slots to spare for them)
@@ -1597,7 +1617,12 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     const float* const e_bias = reinterpret_cast<const float*>(pin_p(p.bias));
     const float* const e_res = reinterpret_cast<const float*>(pin_p(p.res));
     const int e_ldy = pin_i(p.ldy), e_ldr = pin_i(p.ldr), e_acc = pin_i(p.accumulate), e_relu = pin_i(p.relu);
-    const int e_early = pin_i(p.epi_early);
+    const int e_early = pin_i(p.epi_early), e_stat = pin_i(stat ? 1 : 0), e_N = pin_i(p.N);
+    constexpr bool SREG = PF;                                  // per-lane statistics sums kept in registers over the block's tiles
+    const int e_sreg = pin_i((stat && ntn == 1) ? 1 : 0);
+    f32x4 rs1[SREG ? WTN : 1], rs2[SREG ? WTN : 1];
+#pragma unroll
+    for (int n = 0; n < (SREG ? WTN : 1); ++n) rs1[n] = rs2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto fetch_add = [&](const Geom& q) {
       // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image
       const int cxo = q.x0 + r16;
@@ -1637,6 +1662,47 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
       const int ox = cxo - obc * cv_w1, ob = q.b + obc;
       const bool ook = (ox < W) & (obc < cv_nb);
+      if (e_stat) {
+        // per channel tile: this lane's sums over its RPW rows (fp32, RPW terms).  Pixels outside the image contribute nothing.
+        // SREG (one channel tile per pixel tile and registers to spare: the 48- and 64-channel layers, whose tiles are the
+        // shortest): the lane keeps adding into its own fp32 sums over ALL tiles of the block (a block walks a few dozen tiles)
+        // and the cross-lane reduction happens once, at the end of the block (flush_stats).  Otherwise per tile: a 16-lane
+        // row reduction over the tile's 16 columns (row_shr 1, 2, 4, 8 with zero fill: lane 15 of the row ends with the
+        // total, 32 fp32 terms), then ONE fp64 LDS atomic per channel and sum from that lane.
+#pragma unroll
+        for (int n = 0; n < WTN; ++n) {
+          f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < RPW; ++m) {
+            const bool ok = ook & (q.y0 + wave * RPW + m < H);
+            const f32x4 v = acc[n][m] * oscale + add[m][n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ve = ok ? v[e] : 0.f;
+              s1[e] += ve;
+              s2[e] += ve * ve;
+            }
+          }
+          if (SREG && e_sreg) {
+            rs1[n] += s1;
+            rs2[n] += s2;
+            continue;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s1[e] = sp_row16_sum(s1[e]);
+            s2[e] = sp_row16_sum(s2[e]);
+          }
+          if (r16 == 15) {
+            const int c0 = q.nt * BN + 16 * n + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __hip_atomic_fetch_add(lstat + c0 + e, (double)s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(lstat + e_N + c0 + e, (double)s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m;
@@ -1716,6 +1782,19 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       if (!have_next) break;
     }
     for (int k = total; k & (D - 1); ++k) __builtin_amdgcn_s_barrier();      // the producers' loop is unrolled by D slabs
+    if (SREG && e_sreg) {          // the register sums of this wave: row reduction, then one fp64 LDS atomic per channel and sum
+#pragma unroll
+      for (int n = 0; n < WTN; ++n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = sp_row16_sum(rs1[n][e]), b = sp_row16_sum(rs2[n][e]);
+          if (r16 == 15) {
+            __hip_atomic_fetch_add(lstat + 16 * n + 4 * g + e, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(lstat + e_N + 16 * n + 4 * g + e, (double)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
   } else {
     // Producers run a flat loop over the block's slabs (j = 0 .. total-1, indices runtime and wave-uniform): at slab j
     // they store weight slab j+2 (loaded four slabs earlier into register set (j+2)%4) and issue the loads of slab
@@ -1869,6 +1948,14 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummies before the wave ends
   }
+  if (stat) {
+    // every consumer has added its last tile (LDS atomics complete before the barrier); the block's sums go out as row
+    // `block_row` of the partial buffer [rows][2][N], which hrseg_bn_finalize adds up in row order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    double* row = p.stat_partial + (size_t)block_row * 2 * p.N;
+    for (int i = tid; i < 2 * p.N; i += 512) row[i] = lstat[i];
+  }
 }
 
 template <int NS, int TH, int WTN, int CS, int FLIP>
@@ -1876,7 +1963,7 @@ __global__ __launch_bounds__(512) void igemm_patch_ws_kernel(IgemmArgs p, int nt
   __shared__ __attribute__((aligned(16))) unsigned char lds[SpPatchWsLds<NS, TH, WTN, CS>::BYTES];
   const int chunk = (ntotal + gridDim.x - 1) / gridDim.x;
   const int first = blockIdx.x * chunk;
-  igemm_patch_ws_body<NS, TH, WTN, CS, FLIP>(p, lds, first, min(first + chunk, ntotal));
+  igemm_patch_ws_body<NS, TH, WTN, CS, FLIP>(p, lds, first, min(first + chunk, ntotal), blockIdx.x);
 }
 
 // grouped form: every problem runs the wave-specialised body on its own range of persistent blocks (grp.tiles[g]
@@ -1894,10 +1981,10 @@ __global__ __launch_bounds__(512) void igemm_patch_ws_group_kernel(IgemmGroup gr
   const int chunk = (ntotal + nblk - 1) / nblk;
   const int first = local * chunk, end = min(first + chunk, ntotal);
   const int kind = grp.kind[gi];
-  if (kind == 1) igemm_patch_ws_body<NS, 8, 3, 3, FLIP>(grp.a[gi], lds, first, end);
-  else if (kind == 2) igemm_patch_ws_body<NS, 8, 6, 3, FLIP>(grp.a[gi], lds, first, end);
-  else if (kind == 3) igemm_patch_ws_body<NS, 8, 4, 4, FLIP>(grp.a[gi], lds, first, end);
-  else igemm_patch_ws_body<NS, 16, 3, 3, FLIP>(grp.a[gi], lds, first, end);
+  if (kind == 1) igemm_patch_ws_body<NS, 8, 3, 3, FLIP>(grp.a[gi], lds, first, end, local);
+  else if (kind == 2) igemm_patch_ws_body<NS, 8, 6, 3, FLIP>(grp.a[gi], lds, first, end, local);
+  else if (kind == 3) igemm_patch_ws_body<NS, 8, 4, 4, FLIP>(grp.a[gi], lds, first, end, local);
+  else igemm_patch_ws_body<NS, 16, 3, 3, FLIP>(grp.a[gi], lds, first, end, local);
 }
 
 // grouped launch whose problems run either body (the parallel HRNet branches: the wide high-resolution

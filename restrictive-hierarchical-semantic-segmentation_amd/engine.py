@@ -37,6 +37,7 @@ _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the back
 #                takes the raw conv output (same bytes, same kernels) = the ceiling of "BN-apply + ReLU in the consumer's staging"
 #   skip_stats:  no BN-statistics launch in the forward = the ceiling of "statistics in the convolution epilogue"
 _EXPERIMENT = set(filter(None, os.environ.get("HRSEG_EXPERIMENT", "").split(",")))
+_CONV_STATS = os.environ.get("HRSEG_CONV_STATS", "1") != "0"       # 0: BatchNorm statistics always as their own launch
 
 
 def wgrad_stream(device):
@@ -245,14 +246,26 @@ class Recorder:
                 zs = ops.conv_fwd_group([x.data for x in xs], [f[0] for f in folded], [f[1] for f in folded], k, s,
                                         [c.out_channels for _, c, _, _ in items], prec=prec, residuals=res, relus=relus)
             return [Act(z) for z in zs]
+        # training: the convolution kernels that can leave the BatchNorm partial sums of their output behind (the
+        # wave-specialised 3x3 kernels: hrseg_conv_shape_t.stat_partial) -- the statistics launch is then skipped below
+        want_stats = self.training and _CONV_STATS and self.sync is None and not _lib.deterministic() and not _EXPERIMENT
+        stats = None
         if n == 1:
             conv = items[0][1]
-            ys = [ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
-                               k, s, cout=conv.out_channels, prec=self.prec)]
+            ys = ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
+                              k, s, cout=conv.out_channels, prec=self.prec, stats=want_stats)
+            if want_stats:
+                ys, st = ys
+                stats = [st]
+            ys = [ys]
         else:
             ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
                                     [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
-                                    [c.out_channels for _, c, _, _ in items], prec=self.prec)
+                                    [c.out_channels for _, c, _, _ in items], prec=self.prec, stats=want_stats)
+            if want_stats:
+                ys, stats = ys
+        if stats is not None and any(st is None for st in stats):
+            stats = None                                 # (one statistics plan per grouped BatchNorm call)
         # layers with a residual and a ReLU: the backward's mask is not recomputable from y; the forward leaves it as one
         # byte per channel quad (hrseg_bn_fwd_t.relu_mask) so that the backward reads 1/16 of what reading z costs
         masks = [torch.empty((y.shape[0] * y.shape[1] * y.shape[2], y.shape[3] // 4), dtype=torch.uint8, device=y.device)
@@ -262,7 +275,8 @@ class Recorder:
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
                          residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
                          stat_div=self.bn_segments, relu_mask=masks[i],
-                         out=outs[i] if outs is not None else None)
+                         out=outs[i] if outs is not None else None,
+                         partial=stats[i] if stats is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
         if _EXPERIMENT and self.training and self.sync is None:
             phases = 7
@@ -274,7 +288,7 @@ class Recorder:
             if not phases & 4:
                 zc = [(y, c) for y, (_, c) in zip(ys, zc)]
         else:
-            zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync)
+            zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync, phases=6 if stats is not None else 7)
         zs = [Act(z) for z, _ in zc]
         if not self.record:
             return zs

@@ -68,13 +68,26 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False):
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False, stat=None):
     """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h;
-    residual / relu: the forward's fused epilogue y = relu?(conv + bias + residual) (inference with folded BatchNorm)"""
+    residual / relu: the forward's fused epilogue y = relu?(conv + bias + residual) (inference with folded BatchNorm);
+    stat: (device buffer of 256*2*Cout doubles, ctypes int) -- BatchNorm partial sums of the output from the epilogue"""
     B, Hi, Wi, Cin = x_shape
-    return ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
-                     Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec, grad_absmax=ptr(gmax),
-                     residual=ptr(residual), ldr=_ld(residual) if residual is not None else 0, relu=int(bool(relu)))
+    sh = ConvShape(B=B, Hi=Hi, Wi=Wi, Cin=Cin, ldx=ldx, Ho=conv_out_size(Hi, k, s), Wo=conv_out_size(Wi, k, s),
+                   Cout=Cout, ldy=ldy, ksize=k, stride=s, precision=prec, grad_absmax=ptr(gmax),
+                   residual=ptr(residual), ldr=_ld(residual) if residual is not None else 0, relu=int(bool(relu)))
+    if stat is not None:
+        sh.stat_partial = ptr(stat[0])
+        sh.stat_rows = C.pointer(stat[1])
+    return sh
+
+
+STAT_ROWS_MAX = 256          # include/hrseg.h hrseg_conv_shape_t.stat_partial: rows the caller provides
+
+
+def _stat_buffer(cout, device):
+    """(partial-sum buffer for the epilogue statistics of one convolution output, host int that receives the row count)"""
+    return torch.empty(STAT_ROWS_MAX * 2 * cout, dtype=torch.float64, device=device), C.c_int(0)
 
 
 # ------------------------------------------------------------------ convolution
@@ -106,17 +119,22 @@ def _guard_prec(x, prec):
 range_fallbacks = 0
 
 
-def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False):
+def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False, stats=False):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
-    pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions)."""
+    pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions).
+    stats=True: -> (out, (partial, rows) or None): the BatchNorm partial sums of the output where the kernel that ran
+    produces them in its epilogue (hrseg_conv_shape_t.stat_partial), else None"""
     _lib.ensure_scratch(x.device)
     prec = _guard_prec(x, prec)
     B, Hi, Wi, Cin = x.shape
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
-    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu)
+    st = _stat_buffer(Cout, x.device) if stats else None
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu, stat=st)
     call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
+    if stats:
+        return out, ((st[0], st[1].value) if st[1].value > 0 else None)
     return out
 
 
@@ -145,22 +163,25 @@ def _shape_array(shapes):
     return (ConvShape * len(shapes))(*shapes)
 
 
-def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None):
+def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None, stats=False):
     """n independent convolutions (same k, s) in one launch when the library can group them; residuals / relus: the fused
-    epilogue per problem (inference with folded BatchNorm)"""
+    epilogue per problem (inference with folded BatchNorm); stats=True: -> (outs, [(partial, rows) or None per problem])"""
     _lib.ensure_scratch(xs[0].device)
     if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
         prec = _lib.CONV_PRECISION["f32"]        # (one precision per grouped call)
-    outs, shapes = [], []
+    outs, shapes, sts = [], [], []
     for i, (x, co) in enumerate(zip(xs, couts)):
         B, Hi, Wi, Cin = x.shape
         y = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), co, x)
         outs.append(y)
+        sts.append(_stat_buffer(co, x.device) if stats else None)
         shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec, residual=residuals[i] if residuals is not None else None,
-                             relu=relus[i] if relus is not None else False))
+                             relu=relus[i] if relus is not None else False, stat=sts[i]))
     has_bias = any(b is not None for b in biases)
     call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
          _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
+    if stats:
+        return outs, [(st[0], st[1].value) if st[1].value > 0 else None for st in sts]
     return outs
 
 
@@ -324,7 +345,11 @@ def bn_fwd_group(items, training, sync=None, phases=7):
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         a.relu_mask = ptr(it.get("relu_mask"))
         a.stat_ranks = ranks
-        if training:
+        if training and it.get("partial") is not None:
+            part, nch = it["partial"]                   # partial sums left by the convolution's epilogue (phases 6)
+            a.partial, a.nchunks = ptr(part), int(nch)
+            outs.append((z, coef, part))
+        elif training:
             nch = _nchunks(npix, Cn)
             if pool is not None:
                 part = pool[pool_off:pool_off + nch * 2 * Cn]

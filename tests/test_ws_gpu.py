@@ -330,6 +330,64 @@ def test_nine_tap_weight_gradient_matches_torch_and_is_bit_reproducible(cfg):
         assert _rel((a - b0).view(co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), wr.grad) < 4e-5
 
 
+@pytest.mark.parametrize("cfg", ["branches4", "branches2_bias", "single64", "single_canvas"])
+def test_epilogue_statistics_are_the_sums_of_the_output(cfg):
+    """BatchNorm partial sums from the convolution epilogue (hrseg_conv_shape_t.stat_partial): per problem the rows the call
+    reports add up to (sum y, sum y^2) per output channel of the tensor it wrote -- grouped launches with their block
+    partition, ragged tiles, canvas-tiled small images, bias; and BatchNorm on those rows (phases 6) equals BatchNorm with
+    its own statistics launch"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["auto"]          # (grouped launches reach the wave-specialised kernels through the default policy)
+    g = torch.Generator().manual_seed(7)
+    if cfg == "branches4":
+        shapes = [(48, 48, 61, 83, 4), (96, 96, 31, 42, 4), (192, 192, 16, 21, 4), (384, 384, 8, 11, 4)]
+    elif cfg == "branches2_bias":
+        shapes = [(48, 48, 77, 77, 2), (96, 96, 39, 39, 2)]
+    elif cfg == "single64":
+        shapes = [(64, 128, 45, 52, 3)]
+    else:
+        shapes = [(192, 192, 20, 20, 8)]
+    bias = cfg == "branches2_bias"
+    xs = [torch.randn(b, h, w, ci, generator=g).cuda() for ci, co, h, w, b in shapes]
+    ws = [(torch.randn(co, 9, ci, generator=g) * 0.05).cuda() for ci, co, h, w, b in shapes]
+    bs = [(torch.randn(co, generator=g)).cuda() if bias else None for ci, co, h, w, b in shapes]
+    couts = [co for ci, co, h, w, b in shapes]
+    try:
+        _lib.tune(sp_ws_min_tiles=1)
+        _lib.launch_count(None, reset=True)
+        if len(shapes) == 1:
+            y, st = ops.conv_fwd(xs[0], ws[0], bs[0], 3, 1, prec=pr, stats=True)
+            ys, stats = [y], [st]
+        else:
+            ys, stats = ops.conv_fwd_group(xs, ws, bs, 3, 1, couts, prec=pr, stats=True)
+        assert _lib.launch_count("ws") + _lib.launch_count("ws_group") == 1
+        if cfg == "single_canvas":
+            assert _lib.launch_count("ws_canvas") == 1
+    finally:
+        _lib.tune(sp_ws_min_tiles=0)
+    for y, st, co in zip(ys, stats, couts):
+        assert st is not None, "the wave-specialised launch reported no statistics rows"
+        part, rows = st
+        assert 0 < rows <= 256
+        tot = part[:rows * 2 * co].view(rows, 2, co).sum(0).cpu()
+        y64 = y.double().reshape(-1, co).cpu()
+        s1, s2 = y64.sum(0), (y64 * y64).sum(0)
+        assert float((tot[0] - s1).abs().max()) < 1e-5 * float(s2.sqrt().max()) * 30, cfg       # |sum| errors scale with sqrt(n) |y|
+        assert float(((tot[1] - s2) / s2).abs().max()) < 2e-6, cfg
+    # BatchNorm on those rows == BatchNorm with its own statistics phase
+    def bn_items(parts):
+        return [dict(y=y, gamma=torch.ones(co, device="cuda"), beta=torch.zeros(co, device="cuda"),
+                     rm=torch.zeros(co, device="cuda"), rv=torch.ones(co, device="cuda"),
+                     nbt=torch.zeros((), dtype=torch.int64, device="cuda"), momentum=0.1, eps=1e-5, residual=None, relu=True,
+                     partial=p) for y, co, p in zip(ys, couts, parts)]
+    a_items, b_items = bn_items(stats), bn_items([None] * len(ys))
+    za = ops.bn_fwd_group(a_items, True, phases=6)
+    zb = ops.bn_fwd_group(b_items, True)
+    for (z1, c1), (z2, c2), ia, ib in zip(za, zb, a_items, b_items):
+        assert float((z1 - z2).abs().max()) < 2e-5 * max(1.0, float(z2.abs().max()))
+        assert float((ia["rv"] - ib["rv"]).abs().max()) < 1e-6 and float((ia["rm"] - ib["rm"]).abs().max()) < 1e-6
+
+
 BF16_TOL = 6e-3        # operands rounded to bf16 (2^-9 each), fp32 accumulation: 2.2-2.8e-3 measured on these shapes
 
 
