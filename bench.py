@@ -259,7 +259,7 @@ def _csrc_digest():
     return h.hexdigest()[:16]
 
 
-PMC_PROFILE = "r03"
+PMC_PROFILE = "r04"
 
 
 def pmc_value(kernel, what):

@@ -96,6 +96,10 @@ typedef struct {
                                offered in deterministic mode                                                              */
   int* stat_rows;           /* HOST pointer, out (set by the call, synchronously): rows written to stat_partial; 0 = the
                                kernel that ran produces no statistics (run the statistics phase).  Required with stat_partial */
+  int w_persistent;         /* forward / data gradient: the weight operand is a parameter inside one of the ranges registered
+                               with hrseg_set_weight_image_arena, and the caller calls hrseg_weight_images_refresh after every
+                               change of those parameters: the kernels that read pre-split weight images then take the cached
+                               image instead of writing one in front of the launch.  0 (default): never cached            */
 } hrseg_conv_shape_t;
 
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */
@@ -153,6 +157,17 @@ long hrseg_launch_count(const char* family, int reset);
  * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
  * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
 int hrseg_tune(const char* key, int value);
+/* Persistent weight images.  The wave-specialised kernels read their weights from a pre-split image (4 bytes per weight); by
+ * default a small kernel writes it in front of every launch.  With an arena attached -- DEVICE memory the caller owns: `arena`
+ * (256-byte aligned, at least 1 MiB; 8 bytes per parameter covers forward and data-gradient images of a whole model) and
+ * `table` (256-byte aligned, 40 bytes per cached weight) -- the images of weights flagged hrseg_conv_shape_t.w_persistent that lie
+ * in [lo0, hi0) or [lo1, hi1) (the parameter buffer and its transposed copy) are kept: written on first use, and ALL rewritten
+ * by ONE launch of hrseg_weight_images_refresh, which the caller issues whenever those parameters changed (once per train step)
+ * before the convolutions.  Re-attaching (or (NULL, 0, ...)) forgets every cached image.  One arena per process, bound to the
+ * device that was current when it was attached.  Reference ops replaced: none (an implementation detail of nn.Conv2d here). */
+int hrseg_set_weight_image_arena(void* arena, size_t bytes, void* table, size_t table_bytes, const float* lo0, const float* hi0,
+                                 const float* lo1, const float* hi1);
+int hrseg_weight_images_refresh(hrseg_stream_t stream);
 /* Scratch memory for the convolution launches (device, 256-byte aligned, at least 1 MiB; 256 MiB covers every layer
  * of the reference's models): the wave-specialised fp16x2 kernels of the wide 3x3 stride-1 layers read their weights
  * from a pre-split image (4 bytes per weight) that a small kernel writes there right before each launch, on the same

@@ -259,11 +259,12 @@ class _EngineModel(nn.Module):
             self._param_epoch += 1       # running statistics move
         fold = self._fold() if (not self.training and not record) else None
         self._flat.wt_stale = True          # weights may have been updated since the last call
+        wpersist = self._flat.refresh_weight_images(record)     # one launch: every cached weight image for the current weights
         x = x.contiguous().float()
         x_nhwc = None                       # built where a pass needs it (the batched passes build their own stack)
         size = (x.shape[2], x.shape[3])
         if not self._hier():
-            rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync(), fold=fold)
+            rec = Recorder(self.training, record, self._flat, prec=prec, sync=self._bn_sync(), fold=fold, wpersist=wpersist)
             feats = self._backbone(rec, Act(ops.nchw_to_nhwc(x), needs_grad=False))
             z, lv = self._head_forward(rec, feats, self._flat_head(), None, None, size)
             lv.update(rec=rec, groups=None)
@@ -300,7 +301,7 @@ class _EngineModel(nn.Module):
             if batched:
                 if shared is None:
                     rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels, bn_segments=n_levels, prec=prec,
-                                   sync=self._bn_sync())
+                                   sync=self._bn_sync(), wpersist=wpersist)
                     # the image batch stacked L times (library copy kernels: no ATen launch on the path, so a launch
                     # tape of the step is complete)
                     stack = torch.empty((n_levels * Bn, x.shape[2], x.shape[3], x.shape[1]), dtype=torch.float32,
@@ -314,7 +315,7 @@ class _EngineModel(nn.Module):
                 feats.slot = L               # its gradient is rows [L*B, (L+1)*B) of the stacked feature gradient
             elif shared is None:
                 rec = Recorder(self.training, record, self._flat, bn_repeat=n_levels if dedup else 1, prec=prec,
-                               sync=self._bn_sync(), fold=fold)
+                               sync=self._bn_sync(), fold=fold, wpersist=wpersist)
                 if concat and L > 0:
                     # level L re-encodes cat(image, logits_{L-1}) through its own first convolution (cond_stems[L-1])
                     xin = Act(ops.concat_image_logits(x, run.logits[L - 1]), needs_grad=record)

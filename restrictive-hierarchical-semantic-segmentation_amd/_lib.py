@@ -32,7 +32,7 @@ _f = C.c_float
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
     _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")] + \
-               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i), ("stat_partial", _p), ("stat_rows", C.POINTER(C.c_int))]
+               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i), ("stat_partial", _p), ("stat_rows", C.POINTER(C.c_int)), ("w_persistent", _i)]
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
@@ -112,6 +112,7 @@ PROTOTYPES = {
     "hrseg_fill": [_p, _f, _l, _p],
     "hrseg_encode_targets": [_p, _p, C.POINTER(C.c_int), _p, _i, _i, _l, _p],
     "hrseg_combine_levels": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _l, _p],
+    "hrseg_weight_images_refresh": [_p],
 }
 # entry points without the trailing stream argument convention of `call`
 RAW_PROTOTYPES = {
@@ -121,6 +122,7 @@ RAW_PROTOTYPES = {
     "hrseg_comm_wait": [_p, _p],
     "hrseg_comm_destroy": [_p],
     "hrseg_set_scratch": [_p, C.c_size_t],
+    "hrseg_set_weight_image_arena": [_p, C.c_size_t, _p, C.c_size_t, _p, _p, _p, _p],
 }
 
 _lib.hrseg_last_error_string.restype = C.c_char_p
@@ -153,6 +155,30 @@ def ensure_scratch(device):
         return
     _scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
     call_raw("hrseg_set_scratch", _scratch.data_ptr(), nbytes)
+
+
+_image_owner = None
+
+
+def ensure_image_arena(flat):
+    """persistent weight images (hrseg_set_weight_image_arena) for the parameters of `flat` (an engine.FlatParams): the arena
+    -- 8 bytes per parameter: forward and data-gradient images -- and the entry table are tensors owned by `flat`; (re)attached
+    whenever another model's parameters were the registered ones.  HRSEG_WEIGHT_IMAGES=0: off (an image launch per convolution)"""
+    global _image_owner
+    if _image_owner is not None and _image_owner() is flat:
+        return True
+    if os.environ.get("HRSEG_WEIGHT_IMAGES", "1") == "0":
+        return False
+    import torch
+    import weakref
+    if getattr(flat, "_img_arena", None) is None:
+        flat._img_arena = torch.empty(max(1 << 20, 8 * flat.numel + (1 << 20)), dtype=torch.uint8, device=flat.data.device)
+        flat._img_table = torch.empty(40 * 4096, dtype=torch.uint8, device=flat.data.device)
+    d, dt = flat.data, flat.data_t
+    call_raw("hrseg_set_weight_image_arena", flat._img_arena.data_ptr(), flat._img_arena.numel(), flat._img_table.data_ptr(),
+             flat._img_table.numel(), d.data_ptr(), d.data_ptr() + 4 * d.numel(), dt.data_ptr(), dt.data_ptr() + 4 * dt.numel())
+    _image_owner = weakref.ref(flat)      # (weak: the registration must not keep a dead model's buffers alive; only the
+    return True                           #  engine flags weights as persistent, and it re-registers its own model first)
 
 
 _lib.hrseg_tune.restype = _i
@@ -212,7 +238,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 12    # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 13    # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

@@ -28,6 +28,7 @@
 #include "conv_common.h"
 #include "conv_sp.h"
 #include <mutex>
+#include <vector>
 
 // launch counters per kernel family (hrseg_launch_count): the parity tests assert that a case really ran the family
 // it claims to pin (e.g. the wave-specialised kernels on a 64x64 golden with lowered routing thresholds)
@@ -280,32 +281,117 @@ static size_t ws_image_bytes(const IgemmArgs& a, int kind, int ns) {      // ns 
   const int wtn = WS_WTN[kind], cs = WS_CS[kind];
   return (size_t)(a.N / (16 * wtn)) * (a.K / (16 * cs)) * ((9 * cs + 1) / 2) * (size_t)((ns == 4 ? 2 : 1) * 16 * wtn * 64);
 }
-// writes the weight images of n problems (sets a[i].wimg) with one launch; false: no scratch space
+// ---- persistent weight images (hrseg_set_weight_image_arena / hrseg_weight_images_refresh) ------------------------------
+// A weight image depends on the weights alone, and those change once per step: instead of one small image launch in front
+// of every convolution (136 per HRNet step, 5.5 us + a kernel boundary each, all on the critical path) the images of the
+// model's parameters live in an arena the caller owns and are rebuilt by ONE launch when the caller says the weights
+// changed.  An image is cached only for a weight the caller flags as persistent (hrseg_conv_shape_t.w_persistent) AND that
+// lies inside one of the two registered source ranges (the flat parameter buffer and its transposed copy): a scratch tensor
+// that happens to reuse a dead model's addresses never hits.  First use of a weight registers it (and builds its image on
+// the spot, as before); every later refresh rebuilds all registered images.  Single-threaded like the rest of the launch path.
+struct ImgEntry { const float* w; unsigned char* img; int K, N, layout, ns, nblk; float wscale; };
+static std::vector<ImgEntry> g_img;
+static unsigned char* g_img_arena = nullptr;
+static size_t g_img_arena_bytes = 0, g_img_arena_head = 0;
+static WeightImageTabEntry* g_img_tab = nullptr;       // device copy of g_img for the refresh kernel (caller's memory)
+static size_t g_img_tab_cap = 0;
+static bool g_img_dirty = false;
+static const float* g_img_range[4] = {nullptr, nullptr, nullptr, nullptr};
+static int g_img_device = -1;
+extern "C" int hrseg_set_weight_image_arena(void* arena, size_t bytes, void* table, size_t table_bytes, const float* lo0,
+                                            const float* hi0, const float* lo1, const float* hi1) {
+  HRSEG_CHECK_ARG((arena && bytes >= (1u << 20) && table && table_bytes >= sizeof(WeightImageTabEntry)) || (!arena && bytes == 0),
+                  "hrseg_set_weight_image_arena: need an arena of at least 1 MiB and a table, or (null, 0)");
+  HRSEG_CHECK_ARG((((uintptr_t)arena | (uintptr_t)table) & 255) == 0, "hrseg_set_weight_image_arena: buffers must be 256-byte aligned");
+  g_img.clear();
+  g_img_arena = (unsigned char*)arena;
+  g_img_arena_bytes = bytes;
+  g_img_arena_head = 0;
+  g_img_tab = (WeightImageTabEntry*)table;
+  g_img_tab_cap = arena ? table_bytes / sizeof(WeightImageTabEntry) : 0;
+  g_img_dirty = false;
+  g_img_range[0] = lo0; g_img_range[1] = hi0; g_img_range[2] = lo1; g_img_range[3] = hi1;
+  g_img_device = -1;
+  if (arena && hipGetDevice(&g_img_device) != hipSuccess) g_img_device = -1;
+  return 0;
+}
+static bool img_cacheable(const IgemmArgs& a) {
+  if (!g_img_arena || !a.w_persistent) return false;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != g_img_device) return false;
+  return (a.w >= g_img_range[0] && a.w < g_img_range[1]) || (a.w >= g_img_range[2] && a.w < g_img_range[3]);
+}
+extern "C" int hrseg_weight_images_refresh(hrseg_stream_t stream) {
+  if (g_img.empty()) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_img_dirty) {
+    std::vector<WeightImageTabEntry> tab(g_img.size());
+    int end = 0;
+    for (size_t i = 0; i < g_img.size(); ++i) {
+      end += g_img[i].nblk;
+      tab[i] = WeightImageTabEntry{g_img[i].w, g_img[i].img, g_img[i].K, g_img[i].layout, g_img[i].ns, end, g_img[i].wscale, 0};
+    }
+    // (pageable source: the call returns once the table is staged; only after new weights were registered)
+    if (hipMemcpyAsync(g_img_tab, tab.data(), tab.size() * sizeof(WeightImageTabEntry), hipMemcpyHostToDevice, st) != hipSuccess)
+    { hrseg_set_error("hrseg_weight_images_refresh: table upload failed"); return HRSEG_ERR_LAUNCH; }
+    g_img_dirty = false;
+  }
+  int total = 0;
+  for (const auto& e : g_img) total += e.nblk;
+  launch_weight_image_table(g_img_tab, (int)g_img.size(), total, st);
+  HRSEG_LAUNCH_CHECK("weight_image_table");
+  return 0;
+}
+// the weight images of n problems (sets a[i].wimg): cached ones are used as they are, the others are written with one launch
+// (into their new arena slot, or into this stream's scratch ring); false: no scratch space
 static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st, int ns) {
   WeightImageGroup g;
-  g.n = n;
+  g.n = 0;
   g.ns = ns;
   size_t off[MAXG], total = 0;
+  int build[MAXG], nb = 0;
+  unsigned char* dst[MAXG];
   for (int i = 0; i < n; ++i) {
+    dst[i] = nullptr;
+    const int layout = kinds[i] == 4 ? 1 : kinds[i];        // kinds 1 and 4 share the (48, 48) image layout
+    const size_t bytes = (ws_image_bytes(a[i], kinds[i], ns) + 255) & ~(size_t)255;
+    if (img_cacheable(a[i])) {
+      for (const auto& e : g_img)
+        if (e.w == a[i].w && e.layout == layout && e.ns == ns && e.K == a[i].K && e.N == a[i].N && e.wscale == a[i].wscale) { dst[i] = e.img; break; }
+      if (dst[i]) continue;                                  // cached: kept current by hrseg_weight_images_refresh
+      if (g_img_arena_head + bytes <= g_img_arena_bytes && g_img.size() < g_img_tab_cap) {
+        const int wtn = WS_WTN[kinds[i]], cs = WS_CS[kinds[i]];
+        dst[i] = g_img_arena + g_img_arena_head;
+        g_img_arena_head += bytes;
+        g_img.push_back(ImgEntry{a[i].w, dst[i], a[i].K, a[i].N, layout, ns, (a[i].N / (16 * wtn)) * (a[i].K / (16 * cs)) * ((9 * cs + 1) / 2),
+                                 a[i].wscale});
+        g_img_dirty = true;
+        build[nb++] = i;
+        continue;
+      }
+    }
     off[i] = total;
-    total += (ws_image_bytes(a[i], kinds[i], ns) + 255) & ~(size_t)255;
+    total += bytes;
+    build[nb++] = i;
   }
-  unsigned char* base = scratch_reserve(st, total);
-  if (!base) return false;
+  unsigned char* base = total ? scratch_reserve(st, total) : nullptr;
+  if (total && !base) return false;
   int end = 0;
-  for (int i = 0; i < n; ++i) {
-    unsigned char* img = base + off[i];
+  for (int j = 0; j < nb; ++j) {
+    const int i = build[j];
+    if (!dst[i]) dst[i] = base + off[i];
     const int wtn = WS_WTN[kinds[i]], cs = WS_CS[kinds[i]];
     end += (a[i].N / (16 * wtn)) * (a[i].K / (16 * cs)) * ((9 * cs + 1) / 2);
-    g.blk_end[i] = end;
-    g.kind[i] = kinds[i];
-    g.K[i] = a[i].K;
-    g.wscale[i] = a[i].wscale;
-    g.w[i] = a[i].w;
-    g.img[i] = img;
-    a[i].wimg = img;
+    g.blk_end[g.n] = end;
+    g.kind[g.n] = kinds[i];
+    g.K[g.n] = a[i].K;
+    g.wscale[g.n] = a[i].wscale;
+    g.w[g.n] = a[i].w;
+    g.img[g.n] = dst[i];
+    ++g.n;
   }
-  launch_weight_images(g, end, st);
+  for (int i = 0; i < n; ++i) a[i].wimg = dst[i];
+  if (g.n) launch_weight_images(g, end, st);
   return true;
 }
 static int g_ws_epi_early = 1;          // hrseg_tune "ws_epi_early": 0 = the wave-specialised body reads accumulate / residual values at the tile's end
@@ -945,6 +1031,7 @@ static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const fl
   pack_taps(a, a.T, oy, ox, wt);
   set_sp_scales(a, s->precision, nullptr);
   a.res = s->residual; a.ldr = s->ldr; a.relu = s->relu;
+  a.w_persistent = s->w_persistent;
   // BatchNorm statistics in the epilogue: offered to the launchers only where the caller gave both pointers, the output is the
   // BatchNorm's input as stored (no fused residual / ReLU) and the run need not be bit-reproducible
   if (s->stat_partial && s->stat_rows) {
@@ -968,6 +1055,7 @@ static void fill_dgrad_s1_args(IgemmArgs& a, const float* dy, const float* wt, f
   for (int t = 0; t < a.T; ++t) { oy[t] = pad - t / ks; ox[t] = pad - t % ks; wtp[t] = t; }
   pack_taps(a, a.T, oy, ox, wtp);
   set_sp_scales(a, s->precision, s->grad_absmax);
+  a.w_persistent = s->w_persistent;
 }
 
 static void fill_wgrad_args(WgradArgs& a, const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s) {

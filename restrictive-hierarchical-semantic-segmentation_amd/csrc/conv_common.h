@@ -36,6 +36,7 @@ struct IgemmArgs {
   int epi_early;             // wave-specialised body: issue the epilogue's reads (accumulate / residual) ahead of the tile's last slab
   double* stat_partial;      // wave-specialised body, forward: BatchNorm partial sums of the output, one row [2][N] per block (else null)
   int* stat_rows;            // HOST pointer: the launcher writes the number of rows (blocks) there; not read by any kernel
+  int w_persistent;          // w is a parameter the caller keeps images of up to date (hrseg_weight_images_refresh): see conv.hip
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for
@@ -118,6 +119,7 @@ int launch_sp_pgroup_kernel(int ns, const IgemmGroup& g, int wtm, int wtn, int c
 int launch_ws_kernel(const IgemmArgs& a, int kind, int flip, int blocks, int ntotal, hipStream_t st, int ns = 4);    // conv_ws.hip
 int launch_ws_group_kernel(const IgemmGroup& g, int flip, hipStream_t st, int ns = 4);
 int launch_weight_images(const struct WeightImageGroup& g, int nblocks, hipStream_t st);
+int launch_weight_image_table(const struct WeightImageTabEntry* tab, int n, int nblocks, hipStream_t st);
 int launch_wgrad_sp_kernel(int ns, const WgradArgs& a, int tn, int tk, int gx, int tiles, hipStream_t st);     // conv_wgrad_sp.hip
 int launch_wgrad_group_sp(const WgradGroup& g, int tn, int tk, int nblocks, hipStream_t st);
 int launch_wgrad_spw_kernel(const WgradArgs& a, int gx, int tiles, hipStream_t st);

@@ -1450,7 +1450,34 @@ struct WeightImageGroup {
   const float* w[MAXG];
   unsigned char* img[MAXG];
 };
+// table form: the images of EVERY registered convolution weight in one launch (hrseg_weight_images_refresh); the table lives
+// in device memory, a block finds its entry by bisection over the running block counts
+struct WeightImageTabEntry {
+  const float* w;
+  unsigned char* img;
+  int K, kind, ns, blk_end;
+  float wscale;
+  int pad;
+};
 #ifdef HRSEG_TU_WS          // non-template kernels are defined in the one translation unit that launches them
+__global__ __launch_bounds__(256) void sp_weight_image_table_kernel(const WeightImageTabEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= tab[mid].blk_end) lo = mid + 1; else hi = mid;
+  }
+  const WeightImageTabEntry e = tab[lo];
+  const int blk = blockIdx.x - (lo ? tab[lo - 1].blk_end : 0);
+  if (e.ns == 1) {
+    if (e.kind == 2) sp_weight_image_body<1, 6, 3>(e.w, e.img, e.K, e.wscale, blk);
+    else if (e.kind == 3) sp_weight_image_body<1, 4, 4>(e.w, e.img, e.K, e.wscale, blk);
+    else sp_weight_image_body<1, 3, 3>(e.w, e.img, e.K, e.wscale, blk);
+    return;
+  }
+  if (e.kind == 2) sp_weight_image_body<4, 6, 3>(e.w, e.img, e.K, e.wscale, blk);
+  else if (e.kind == 3) sp_weight_image_body<4, 4, 4>(e.w, e.img, e.K, e.wscale, blk);
+  else sp_weight_image_body<4, 3, 3>(e.w, e.img, e.K, e.wscale, blk);
+}
 __global__ __launch_bounds__(256) void sp_weight_image_kernel(WeightImageGroup g) {
   int gi = 0;
   while (gi + 1 < g.n && (int)blockIdx.x >= g.blk_end[gi]) ++gi;

@@ -8,6 +8,10 @@ int launch_weight_images(const WeightImageGroup& g, int nblocks, hipStream_t st)
   hipLaunchKernelGGL(sp_weight_image_kernel, dim3(nblocks), dim3(256), 0, st, g);
   return 0;
 }
+int launch_weight_image_table(const WeightImageTabEntry* tab, int n, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(sp_weight_image_table_kernel, dim3(nblocks), dim3(256), 0, st, tab, n);
+  return 0;
+}
 int launch_ws_kernel(const IgemmArgs& a, int kind, int flip, int blocks, int ntotal, hipStream_t st, int ns) {
   const dim3 grid((unsigned)blocks);
 #define WS1(NS_, K_, H_, N_, C_) if (ns == NS_ && kind == K_) { \

@@ -126,15 +126,30 @@ class FlatParams:
         self._wt_entries = len(entries)
         self.wt_stale = True
 
-    def transposed(self, p):
-        """[Cin][taps][Cout] copy of conv weight p (valid until the next forward)"""
+    def transpose_all(self):
         if self.wt_stale:
             if self._wt_table is not None:
                 ops.call("hrseg_weight_transpose_all", ops.ptr(self.data), ops.ptr(self.data_t), ops.ptr(self._wt_table),
                          self._wt_entries)
             self.wt_stale = False
+
+    def transposed(self, p):
+        """[Cin][taps][Cout] copy of conv weight p (valid until the next forward)"""
+        self.transpose_all()
         lo, hi = p._hr_tstore_range
         return self.data_t[lo:hi]
+
+    def refresh_weight_images(self, backward):
+        """start of a model call: the pre-split weight images the wave-specialised kernels read are rebuilt for the current
+        parameters by ONE launch (hrseg_weight_images_refresh) instead of one small launch in front of every convolution;
+        `backward`: the call will run a reverse pass, so the transposed weights (the data gradients' operand) are produced
+        first and their images refreshed with the rest.  -> whether the convolutions may flag their weights as persistent"""
+        if not _lib.ensure_image_arena(self):
+            return False
+        if backward:
+            self.transpose_all()
+        ops.call("hrseg_weight_images_refresh")
+        return True
 
     def view_of(self, flat_tensor, p):
         """the slice of another flat buffer (optimizer moments ...) that belongs to parameter p, in p's
@@ -166,7 +181,8 @@ class FlatParams:
 class Recorder:
     """Forward launcher + tape of backward closures for ONE model forward."""
 
-    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0, sync=None, fold=None):
+    def __init__(self, training, record, flat=None, bn_repeat=1, bn_segments=1, prec=0, sync=None, fold=None, wpersist=False):
+        self.wpersist = bool(wpersist) and flat is not None      # weights of the flat buffers have cached images (hrseg.h w_persistent)
         self.fold = fold                 # inference: (conv, bn) -> (folded weight, folded bias), or None = BN as its own launches
         self.sync = sync                 # process group for cross-rank BatchNorm statistics (opt-in sync_bn), else None
         self.prec = prec                 # _lib.CONV_PRECISION code of every convolution of this forward (and its backward)
@@ -253,7 +269,7 @@ class Recorder:
         if n == 1:
             conv = items[0][1]
             ys = ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
-                              k, s, cout=conv.out_channels, prec=self.prec, stats=want_stats)
+                              k, s, cout=conv.out_channels, prec=self.prec, stats=want_stats, wpersist=self.wpersist)
             if want_stats:
                 ys, st = ys
                 stats = [st]
@@ -261,7 +277,8 @@ class Recorder:
         else:
             ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
                                     [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
-                                    [c.out_channels for _, c, _, _ in items], prec=self.prec, stats=want_stats)
+                                    [c.out_channels for _, c, _, _ in items], prec=self.prec, stats=want_stats,
+                                    wpersist=self.wpersist)
             if want_stats:
                 ys, stats = ys
         if stats is not None and any(st is None for st in stats):
@@ -355,17 +372,20 @@ class Recorder:
                 if len(rnd) == 1:
                     i = rnd[0]
                     x = xs[i]
+                    wp = self.wpersist and hasattr(items[i][1].weight, "_hr_tstore_range")
                     if x.grad is None:
                         x.grad = ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, prec=self.prec,
-                                                gmax=gmaxs[i])
+                                                gmax=gmaxs[i], wpersist=wp)
                     else:
                         ops.conv_dgrad(dys[i], self._wt(items[i][1]), x.data.shape, k, s, out=x.grad, accumulate=True,
-                                       prec=self.prec, gmax=gmaxs[i])
+                                       prec=self.prec, gmax=gmaxs[i], wpersist=wp)
                 else:
                     got = ops.conv_dgrad_group([dys[i] for i in rnd], [self._wt(items[i][1]) for i in rnd],
                                                [xs[i].data.shape for i in rnd], k, s, [xs[i].grad for i in rnd],
                                                [xs[i].grad is not None for i in rnd], prec=self.prec,
-                                               gmaxs=[gmaxs[i] for i in rnd])
+                                               gmaxs=[gmaxs[i] for i in rnd],
+                                               wpersist=self.wpersist and all(hasattr(items[i][1].weight, "_hr_tstore_range")
+                                                                              for i in rnd))
                     for i, o in zip(rnd, got):
                         xs[i].grad = o
                 todo = rest

@@ -68,7 +68,7 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False, stat=None):
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False, stat=None, wpersist=False):
     """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h;
     residual / relu: the forward's fused epilogue y = relu?(conv + bias + residual) (inference with folded BatchNorm);
     stat: (device buffer of 256*2*Cout doubles, ctypes int) -- BatchNorm partial sums of the output from the epilogue"""
@@ -79,6 +79,7 @@ def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu
     if stat is not None:
         sh.stat_partial = ptr(stat[0])
         sh.stat_rows = C.pointer(stat[1])
+    sh.w_persistent = int(bool(wpersist))
     return sh
 
 
@@ -119,7 +120,7 @@ def _guard_prec(x, prec):
 range_fallbacks = 0
 
 
-def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False, stats=False):
+def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False, stats=False, wpersist=False):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
     pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions).
     stats=True: -> (out, (partial, rows) or None): the BatchNorm partial sums of the output where the kernel that ran
@@ -131,21 +132,21 @@ def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
     st = _stat_buffer(Cout, x.device) if stats else None
-    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu, stat=st)
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu, stat=st, wpersist=wpersist)
     call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
     if stats:
         return out, ((st[0], st[1].value) if st[1].value > 0 else None)
     return out
 
 
-def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=None):
+def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=None, wpersist=False):
     """wt = weight_transpose(w): [Cin][k*k][Cout]."""
     _lib.ensure_scratch(dy.device)
     B, Hi, Wi, Cin = x_shape
     if out is None:
         out = empty_nhwc(B, Hi, Wi, Cin, dy)
         accumulate = False
-    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s, prec, gmax)
+    sh = _shape(x_shape, _ld(out), dy.shape[3], _ld(dy), k, s, prec, gmax, wpersist=wpersist)
     call("hrseg_conv_dgrad", ptr(dy), ptr(wt), ptr(out), int(accumulate), C.byref(sh))
     return out
 
@@ -163,7 +164,7 @@ def _shape_array(shapes):
     return (ConvShape * len(shapes))(*shapes)
 
 
-def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None, stats=False):
+def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None, stats=False, wpersist=False):
     """n independent convolutions (same k, s) in one launch when the library can group them; residuals / relus: the fused
     epilogue per problem (inference with folded BatchNorm); stats=True: -> (outs, [(partial, rows) or None per problem])"""
     _lib.ensure_scratch(xs[0].device)
@@ -176,7 +177,7 @@ def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=No
         outs.append(y)
         sts.append(_stat_buffer(co, x.device) if stats else None)
         shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec, residual=residuals[i] if residuals is not None else None,
-                             relu=relus[i] if relus is not None else False, stat=sts[i]))
+                             relu=relus[i] if relus is not None else False, stat=sts[i], wpersist=wpersist))
     has_bias = any(b is not None for b in biases)
     call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
          _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
@@ -185,7 +186,7 @@ def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=No
     return outs
 
 
-def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=None):
+def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=None, wpersist=False):
     """outs[i] None -> allocated (accumulate ignored)"""
     _lib.ensure_scratch(dys[0].device)
     outs, acc, shapes = list(outs), list(accumulate), []
@@ -193,7 +194,8 @@ def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=N
         if outs[i] is None:
             outs[i] = empty_nhwc(xs[0], xs[1], xs[2], xs[3], dy)
             acc[i] = False
-        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s, prec, gmaxs[i] if gmaxs is not None else None))
+        shapes.append(_shape(xs, _ld(outs[i]), dy.shape[3], _ld(dy), k, s, prec, gmaxs[i] if gmaxs is not None else None,
+                             wpersist=wpersist))
     call("hrseg_conv_dgrad_group", len(dys), _lib.ptr_array(dys), _lib.ptr_array(wts), _lib.ptr_array(outs),
          _lib.int_array([int(a) for a in acc]), _shape_array(shapes))
     return outs

@@ -390,6 +390,7 @@ class TapedTrainStep:
         optimizer._moments()
         optimizer._sync_hyper(dev)
         _lib.ensure_scratch(dev)
+        _lib.ensure_image_arena(m._flat)
         self.pool = torch.cuda.MemPool()
         self.tape = _lib.Tape()
         self.replays = 0

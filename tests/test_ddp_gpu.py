@@ -164,6 +164,60 @@ def test_two_rank_dice_equals_the_gathered_batch_dice(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# the recorded launch tape under data parallelism: host callbacks (bucketed all-reduce, Dice divisor) at their tape positions
+def _tape_worker(rank, world, port, name, out_dir, taped):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HRSEG_WGRAD_STREAM="0", HRSEG_DETERMINISTIC="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hrseg_amd import train as PT
+    from hrseg_amd.parallel import GradSync
+    model, args, tree, fns, x, t = _setup(name)
+    t = t.clone()
+    t[3, 4:] = -1.0                                       # rank 1 holds a sample without a valid Dice item at level 1
+    sync = GradSync(model)
+    opt = PT.FusedAdamW(model, lr=[1e-3])
+    opt.grad_scale = 1.0 / world
+    sl = slice(rank * PER_RANK, (rank + 1) * PER_RANK)
+    xs = [x[sl], (x[sl] * 0.9).contiguous(), x[sl].flip(-1).contiguous()]
+    losses, step = [], None
+    for i, xi in enumerate(xs):
+        if not taped:
+            loss, _ = PT.train_step(model, opt, xi, t[sl], fns, args, tree, [])
+            losses.append(float(loss))
+        else:
+            if step is None:
+                step = PT.TapedTrainStep(model, opt, fns, args, tree, xi, t[sl])
+                packed, _ = step.result()
+            else:
+                packed, _ = step(xi, t[sl])
+            losses.append(step.unpack(packed.tolist())[0])
+    torch.cuda.synchronize()
+    if taped:
+        assert step.replays == 2 and step.synced and len(sync.launched) >= 2
+    tag = "tape" if taped else "eager"
+    np.save(os.path.join(out_dir, f"{tag}_grad{rank}.npy"), model._flat.grad.cpu().numpy())
+    np.save(os.path.join(out_dir, f"{tag}_data{rank}.npy"), model._flat.data.cpu().numpy())
+    np.save(os.path.join(out_dir, f"{tag}_loss{rank}.npy"), np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_taped_step_is_the_two_rank_eager_step(tmp_path):
+    """three steps on two ranks, once through train_step and once through TapedTrainStep (recording run + two replays): the
+    all-reduce buckets and the Dice divisor exchange are host callbacks of the tape and must run at their positions in
+    every replay -- same losses, same all-reduced gradients, same weights, bit for bit (deterministic mode)"""
+    name = "unet_hier_tl_62"
+    for i, taped in enumerate((False, True)):
+        port = 29700 + (os.getpid() % 200) + 200 * i
+        mp.spawn(_tape_worker, args=(2, port, name, str(tmp_path), taped), nprocs=2, join=True)
+    for rank in range(2):
+        for what in ("grad", "data", "loss"):
+            a, b = np.load(tmp_path / f"eager_{what}{rank}.npy"), np.load(tmp_path / f"tape_{what}{rank}.npy")
+            assert np.array_equal(a, b), (what, rank, np.abs(a - b).max())
+    assert np.array_equal(np.load(tmp_path / "tape_data0.npy"), np.load(tmp_path / "tape_data1.npy"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # opt-in synchronised BatchNorm (SURVEY 8(f4)): statistics over all ranks
 def _syncbn_worker(rank, world, port, name, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

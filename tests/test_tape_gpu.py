@@ -177,3 +177,40 @@ def test_train_epoch_is_the_same_epoch_with_and_without_the_tape(monkeypatch):
             assert torch.equal(sa[k], sb[k]), k
     finally:
         _lib.set_deterministic(False)
+
+
+@pytest.mark.parametrize("name", ["hrnet_hier_tl_64", "unet_hier_tl_62"])
+def test_cached_weight_images_follow_the_weights(name, monkeypatch):
+    """persistent weight images (hrseg_set_weight_image_arena: one refresh launch per model call instead of an image launch in
+    front of every convolution) against the per-convolution images (HRSEG_WEIGHT_IMAGES=0): three steps at a LARGE learning
+    rate, so that a stale image would show at once -- same bits in deterministic mode, eager and taped"""
+    from hrseg_amd import _lib, train as PT
+    from tests.helpers import conv_mode
+    _lib.set_deterministic(True)
+    try:
+        res = {}
+        for images, taped in (("1", False), ("0", False), ("1", True)):
+            monkeypatch.setenv("HRSEG_WEIGHT_IMAGES", images)
+            model, opt, fns, args, tree, g = _setup(name, lr=3e-2)
+            bs = _batches(g, 3)
+            losses, step = [], None
+            with conv_mode(model, "auto_ws") as cm:          # (the wave-specialised kernels at golden sizes)
+                for x, t in bs:
+                    if not taped:
+                        losses.append(float(PT.train_step(model, opt, x, t, fns, args, tree, [])[0]))
+                    elif step is None:
+                        step = PT.TapedTrainStep(model, opt, fns, args, tree, x, t)
+                        losses.append(step.unpack(step.result()[0].tolist())[0])
+                    else:
+                        losses.append(step.unpack(step(x, t)[0].tolist())[0])
+                torch.cuda.synchronize()
+            assert cm.counts["ws"] + cm.counts["ws_group"] > 0
+            res[(images, taped)] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        base = res[("0", False)]
+        for key in (("1", False), ("1", True)):
+            assert res[key][0] == base[0], (key, res[key][0], base[0])
+            for k, v in base[1].items():
+                assert torch.equal(res[key][1][k], v), (key, k)
+        assert abs(base[0][0] - base[0][2]) > 1e-3 * abs(base[0][0])       # the steps did move the loss
+    finally:
+        _lib.set_deterministic(False)
