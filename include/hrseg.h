@@ -15,7 +15,10 @@
  *     from several threads); the scratch buffer attached with hrseg_set_scratch
  *     (ONE buffer per process, bound to the device that was current when it was
  *     attached -- launches on another device do not use it -- whose region table
- *     is mutex-protected); the launch counters of hrseg_launch_count.
+ *     is mutex-protected); the weight-image arena attached with
+ *     hrseg_set_weight_image_arena and its host-side table of cached weights (one
+ *     per process and device, touched only from the launching thread); the launch
+ *     counters of hrseg_launch_count.
  *   - activations are NHWC fp32, addressed as pixel*ld + channel ("ld" =
  *     floats per pixel row, >= C, multiple of 4) so a kernel can read or
  *     write a channel slice of a wider tensor (concat without a copy).
