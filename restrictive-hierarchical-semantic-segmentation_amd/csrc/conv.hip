@@ -245,7 +245,8 @@ static long ws_pixel_tiles(const IgemmArgs& a, int kind, bool canvas) {       //
 }
 static bool ws_canvas(const IgemmArgs& a, int kind) {
   if (!g_ws_canvas || a.B < 2 || (long)a.B * (a.Wo + 1) >= 65536) return false;
-  if ((long)a.B * a.Ho * a.Wo * a.ldx * 4 >= (1l << 31)) return false;          // one buffer descriptor spans the batch
+  const long ldmax = a.ldx > a.ldy ? (a.ldx > a.ldr ? a.ldx : a.ldr) : (a.ldy > a.ldr ? a.ldy : a.ldr);
+  if ((long)a.B * a.Ho * a.Wo * ldmax * 4 >= (1l << 31)) return false;          // one buffer descriptor (input, output, residual) spans the batch
   return ws_pixel_tiles(a, kind, true) * 100 <= ws_pixel_tiles(a, kind, false) * (100 - g_ws_canvas);
 }
 static long ws_tiles(const IgemmArgs& a, int kind) {
@@ -266,6 +267,10 @@ static int ws_kind(const IgemmArgs& a) {
   if (!g_sp_ws || !scratch_usable() || patch_flip(a) < 0 || a.T != 9 || a.sy != 1 || a.sx != 1 || !a.direct_out || a.Hi != a.Ho || a.Wi != a.Wo)
     return 0;
   if (a.oy_min != -1 || a.ox_min != -1) return 0;
+  {   // 32-bit byte offsets inside one image (input patch, output, residual)
+    const long ldmax = a.ldx > a.ldy ? (a.ldx > a.ldr ? a.ldx : a.ldr) : (a.ldy > a.ldr ? a.ldy : a.ldr);
+    if ((double)a.Ho * a.Wo * (double)ldmax * 4.0 >= 4294967040.0) return 0;
+  }
   int kind = (a.K % 48 == 0 && a.N % 48 == 0) ? 1 : (a.K % 64 == 0 && a.N % 64 == 0) ? 3 : 0;
   if (!kind) return 0;
   if (kind == 1) {      // the tiling is chosen on the per-image tile counts (a size class of the problem), canvas or not

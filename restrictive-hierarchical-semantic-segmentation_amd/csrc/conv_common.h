@@ -57,6 +57,7 @@ __device__ __forceinline__ int fdiv(int n, int d, float rcp) {
 // 115), and the conv kernels gain 10-13 % (tools/ubench/depth_lab.hip).  The descriptor's range
 // check also gives the zero padding for free: a lane outside the image uses offset 0xFFFFFFFF.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define HRSEG_BUF_FLAGS 0x00020000      // raw buffer, 32-bit data format (gfx9 family word 3)
 #define HRSEG_BUF_OOB 0xFFFFFFFFu
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
@@ -65,6 +66,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_bytes) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff_bytes, 0));
+}
+// ... and stores: a lane whose offset is HRSEG_BUF_OOB writes nothing (no exec-mask branch around the store)
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff_bytes, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)voff, soff_bytes, 0);
 }
 
 // swizzle of the 16-byte slot inside a 64-byte LDS row so that every 16-lane

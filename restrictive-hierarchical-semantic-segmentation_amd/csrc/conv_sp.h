@@ -1650,12 +1650,24 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     f32x4 rs1[SREG ? WTN : 1], rs2[SREG ? WTN : 1];
 #pragma unroll
     for (int n = 0; n < (SREG ? WTN : 1); ++n) rs1[n] = rs2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto fetch_add = [&](const Geom& q) {
+    // Output addressing: buffer descriptors based at the tile's first image (canvas mode: the cv_nb images of the canvas), 32-bit
+    // byte offsets per lane, HRSEG_BUF_OOB for a pixel outside the image -- its load returns zeros, its store writes nothing: no
+    // exec-mask branch per output row and no 64-bit address arithmetic in an epilogue that runs with the matrix pipe idle.
+    // (Host-checked: cv_nb * H * W * ld * 4 bytes < 2^31 for y and the residual, conv.hip ws_kind / ws_canvas.)
+    const unsigned ldy4 = (unsigned)e_ldy * 4u, ldr4 = (unsigned)e_ldr * 4u;
+    auto tile_offsets = [&](const Geom& q, unsigned ld4, unsigned (&off)[RPW]) {
       // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image
       const int cxo = q.x0 + r16;
       const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
-      const int ox = cxo - obc * cv_w1, ob = q.b + obc;
+      const int ox = cxo - obc * cv_w1;
       const bool ook = (ox < W) & (obc < cv_nb);
+#pragma unroll
+      for (int m = 0; m < RPW; ++m) {
+        const int oy = q.y0 + wave * RPW + m;
+        off[m] = (ook & (oy < H)) ? (unsigned)((obc * H + oy) * W + ox) * ld4 + (unsigned)(q.nt * BN + 4 * g) * 4u : HRSEG_BUF_OOB;
+      }
+    };
+    auto fetch_add = [&](const Geom& q) {
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1664,31 +1676,28 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
         for (int m = 0; m < RPW; ++m) add[m][n] = bv;
       }
       if (e_acc) {
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(e_y + (size_t)q.b * H * W * e_ldy, (size_t)cv_nb * H * W * ldy4);
+        unsigned off[RPW];
+        tile_offsets(q, ldy4, off);
 #pragma unroll
-        for (int m = 0; m < RPW; ++m) {
-          const int oy = q.y0 + wave * RPW + m;
-          if (oy >= H || !ook) continue;
-          const float* yrow = e_y + ((size_t)(ob * H + oy) * W + ox) * e_ldy;
+        for (int m = 0; m < RPW; ++m)
 #pragma unroll
-          for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g);
-        }
+          for (int n = 0; n < WTN; ++n) add[m][n] += buf_load4(ry, off[m], 64 * n);
       }
       if (e_res) {
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(e_res + (size_t)q.b * H * W * e_ldr, (size_t)cv_nb * H * W * ldr4);
+        unsigned off[RPW];
+        tile_offsets(q, ldr4, off);
 #pragma unroll
-        for (int m = 0; m < RPW; ++m) {
-          const int oy = q.y0 + wave * RPW + m;
-          if (oy >= H || !ook) continue;
-          const float* rrow = e_res + ((size_t)(ob * H + oy) * W + ox) * e_ldr;
+        for (int m = 0; m < RPW; ++m)
 #pragma unroll
-          for (int n = 0; n < WTN; ++n) add[m][n] += *reinterpret_cast<const f32x4*>(rrow + q.nt * BN + 16 * n + 4 * g);
-        }
+          for (int n = 0; n < WTN; ++n) add[m][n] += buf_load4(rr, off[m], 64 * n);
       }
     };
     auto store_acc = [&](const Geom& q) {
-      const int cxo = q.x0 + r16;
-      const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
-      const int ox = cxo - obc * cv_w1, ob = q.b + obc;
-      const bool ook = (ox < W) & (obc < cv_nb);
+      const __amdgpu_buffer_rsrc_t ry = make_rsrc(e_y + (size_t)q.b * H * W * e_ldy, (size_t)cv_nb * H * W * ldy4);
+      unsigned off[RPW];
+      tile_offsets(q, ldy4, off);
       if (e_stat) {
         // per channel tile: this lane's sums over its RPW rows (fp32, RPW terms).  Pixels outside the image contribute nothing.
         // SREG (one channel tile per pixel tile and registers to spare: the 48- and 64-channel layers, whose tiles are the
@@ -1701,7 +1710,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int m = 0; m < RPW; ++m) {
-            const bool ok = ook & (q.y0 + wave * RPW + m < H);
+            const bool ok = off[m] != HRSEG_BUF_OOB;
             const f32x4 v = acc[n][m] * oscale + add[m][n];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1732,9 +1741,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
-        const int oy = q.y0 + wave * RPW + m;
-        if (oy >= H || !ook) continue;
-        float* yrow = e_y + ((size_t)(ob * H + oy) * W + ox) * e_ldy;
 #pragma unroll
         for (int n = 0; n < WTN; ++n) {
           f32x4 v = acc[n][m] * oscale + add[m][n];
@@ -1742,7 +1748,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
-          *reinterpret_cast<f32x4*>(yrow + q.nt * BN + 16 * n + 4 * g) = v;
+          buf_store4(ry, off[m], 64 * n, v);
         }
       }
     };
