@@ -36,6 +36,7 @@ _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the back
 #   skip_apply1: no BN-apply launch for tensors with a single convolution reader (conv1 -> conv2 of a BasicBlock): the reader
 #                takes the raw conv output (same bytes, same kernels) = the ceiling of "BN-apply + ReLU in the consumer's staging"
 #   skip_stats:  no BN-statistics launch in the forward = the ceiling of "statistics in the convolution epilogue"
+#   skip_wgrad:  no weight-gradient launch at all = what the side stream's work costs the step beside the main chain
 _EXPERIMENT = set(filter(None, os.environ.get("HRSEG_EXPERIMENT", "").split(",")))
 _CONV_STATS = os.environ.get("HRSEG_CONV_STATS", "1") != "0"       # 0: BatchNorm statistics always as their own launch
 
@@ -339,6 +340,8 @@ class Recorder:
             # the weight gradient is issued on the side stream BEFORE the data gradient of the same layer (issuing it behind,
             # so that it would run beside the next BatchNorm backward, measured 55.9 vs 53.8 ms per step)
             def weight_gradients():
+                if "skip_wgrad" in _EXPERIMENT:      # (measurement only: what the weight gradients cost the step beside the main chain)
+                    return
                 side = wgrad_stream(dys[0].device)
                 if side is not None:
                     _lib.stream_wait(side, None)
