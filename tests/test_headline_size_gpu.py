@@ -183,3 +183,49 @@ def test_configs0_flat_unet_b2_128_tracks_the_oracle():
             assert float((a - b).norm()) < 1e-2 * float(b.norm()) + 1e-5, n
         else:
             assert float((a - b).abs().max()) < 4.5e-4 + 1e-3 * float(b.abs().max()), n
+
+
+# Measured on hrnet_hier_tl_620_b2: logits L2 error 0.326 (level 0) / 0.155 (level 1), arg-max agreement 0.822 / 0.945, loss
+# within 1.2e-3.  bf16 operands (2^-9 each) through ~300 conv + BN layers of a RANDOM-INIT net, whose logits sit close to ties:
+# the error is the arithmetic's own (the 62-pixel golden shows the same 0.32 on level 0), not small-sample BatchNorm chaos.
+# Bars = measured + 25 %.
+BF16_620_LOGIT_L2 = 0.41
+BF16_620_ARGMAX_AGREEMENT = 0.78
+BF16_620_LOSS = 3e-3
+
+
+def test_bf16_convolutions_at_the_headline_size():
+    """BASELINE configs[4] arithmetic (model.conv_dtype = 'bf16': bf16 operands, fp32 accumulate; explicitly outside the 1e-3
+    bar) against the reference fixture at 620 x 620: how far the opt-in bf16 step is from the fp32 reference where it matters"""
+    from hrseg_amd.Models import models as PM
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
+    from hrseg_amd.utils import synth
+    name = "hrnet_hier_tl_620_b2"
+    g = load_golden(name)
+    tree = load_tree("class_tree_tl.json")
+    size, batch, seed, lat = int(g["size"]), int(g["batch"]), int(g["seed"]), int(g["lattice"])
+    x_np, t_np = synth.synthetic_batch(tree, batch, size, seed=seed, hierarchical=True)
+    weights = level_weights_for("class_tree_tl.json", True)
+    args = argparse.Namespace(model_type=1, model_select=1, num_classes=[4, 4], level_weights=weights,
+                              level0_pretrain_epochs=None, batch_size=batch)
+    model = build_model(PM, "hrnet", True, tree, size).cuda()
+    model.conv_dtype = "bf16"
+    model.train()
+    x, target = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
+    sl = (slice(None), slice(None), slice(0, None, lat), slice(0, None, lat))
+    _, logits = PT._model_call(model, x, args, tree)
+    l2, agree, loss = [], [], 0.0
+    for L, (z, t) in enumerate(zip(logits, PT.split_targets(target, args))):
+        got, ref = z.detach()[sl].cpu().numpy().astype(np.float64), g[f"logits{L}"].astype(np.float64)
+        l2.append(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+        agree.append(float((got.argmax(1) == ref.argmax(1)).mean()))
+        res = PL.fused_ce_dice(z, t, weights[L])
+        loss = loss + res[0] + res[1]
+    want = sum(float(g[f"ce{L}"]) + float(g[f"dice{L}"]) for L in range(2))
+    print(f"bf16 at 620x620: logits L2 error {['%.3e' % v for v in l2]}, arg-max agreement {['%.4f' % v for v in agree]}, "
+          f"loss {float(loss):.6f} vs {want:.6f} ({abs(float(loss) - want) / want:.2e})")
+    assert max(l2) < BF16_620_LOGIT_L2 and min(agree) > BF16_620_ARGMAX_AGREEMENT, (l2, agree)
+    assert abs(float(loss) - want) < BF16_620_LOSS * abs(want)
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

@@ -207,9 +207,11 @@ def test_wide_tile_weight_gradient_body(k, s_):
 
 # ------------------------------------------------------------------ BASELINE configs[4]: bf16-input convolutions
 # bf16 operands (2^-9 each) through ~300 conv+BN layers at 62x62, where the lowest branch is 2x2 pixels and BatchNorm
-# normalises over 8 samples: measured relative L2 error of the logits 0.10-0.31 (level 0 worst), max-norm error up to 0.47 on single pixels, loss within 0.1 %
-BF16_LOGIT_L2_TOL = 0.5
-BF16_ARGMAX_AGREEMENT = 0.85
+# normalises over 8 samples: measured relative L2 error of the logits 0.106-0.322 (level 0 worst), max-norm error up to 0.45 on single
+# pixels, arg-max agreement 0.910-1.000, loss within 0.1 %; the 620 x 620 fixture shows the same level-0 error (tests/
+# test_headline_size_gpu.py), so this is bf16 arithmetic on a random-init net.  Bars = measured + 25 %.
+BF16_LOGIT_L2_TOL = 0.40
+BF16_ARGMAX_AGREEMENT = 0.8875
 
 
 def test_bf16_convs_on_the_extended_tree_golden():
