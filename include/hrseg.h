@@ -99,12 +99,20 @@ typedef struct {
                                offered in deterministic mode                                                              */
   int* stat_rows;           /* HOST pointer, out (set by the call, synchronously): rows written to stat_partial; 0 = the
                                kernel that ran produces no statistics (run the statistics phase).  Required with stat_partial */
+  int x_split;              /* forward / weight gradient: x is stored PRE-SPLIT (hrseg_bn_fwd_t.z_split wrote it: per 4 channels the
+                               dwords {hi01, hi23, lo01, lo23} of the fp16x2 split).  Only the wave-specialised forward kernels and
+                               the nine-tap weight gradient read that form: ask hrseg_conv_x_split_ok first; a call that cannot
+                               take those kernels FAILS (HRSEG_ERR_UNSUPPORTED), it never reads the bytes as fp32           */
   int w_persistent;         /* forward / data gradient: the weight operand is a parameter inside one of the ranges registered
                                with hrseg_set_weight_image_arena, and the caller calls hrseg_weight_images_refresh after every
                                change of those parameters: the kernels that read pre-split weight images then take the cached
                                image instead of writing one in front of the launch.  0 (default): never cached            */
 } hrseg_conv_shape_t;
 
+/* 1 when the forward call hrseg_conv_fwd(_group)(n, shapes) would run the wave-specialised kernels for EVERY problem and
+ * hrseg_conv_wgrad_group_ws would run the nine-tap kernel for all of them, i.e. when the producer of x may store it pre-split
+ * (x_split); 0 otherwise.  Pure host logic on the shapes, the attached scratch / tuning state and the precision.           */
+int hrseg_conv_x_split_ok(int n, const hrseg_conv_shape_t* shapes);
 /* y = conv(x, w) + bias.  w: [Cout][k*k][Cin]; bias may be NULL. */
 int hrseg_conv_fwd(const float* x, const float* w, const float* bias, float* y,
                    const hrseg_conv_shape_t* s, hrseg_stream_t stream);
@@ -245,6 +253,9 @@ typedef struct {
   unsigned char* relu_mask;                          /* optional out, [npix][C/4] bytes: bit j of byte (pixel, q) =
                                                         channel 4q+j passed the ReLU; the backward of a layer WITH a
                                                         residual reads it (hrseg_bn_bwd_t.relu_mask) instead of z    */
+  int z_split;                                       /* != 0: z is written PRE-SPLIT for fp16x2 convolutions (per 4
+                                                        channels {hi01, hi23, lo01, lo23}, same 16 bytes): only for a
+                                                        tensor whose every reader takes hrseg_conv_shape_t.x_split */
   int stat_ranks;                                    /* cross-rank statistics (opt-in synchronised BN): the
                                                         partial sums were all-reduced over this many ranks of
                                                         equal shards between the statistics and the finalize

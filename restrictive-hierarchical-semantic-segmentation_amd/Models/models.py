@@ -453,7 +453,7 @@ class double_conv(nn.Module):
                                   Conv2d(out_ch, out_ch, 3, padding=1), BatchNorm2d(out_ch), nn.ReLU(inplace=True))
 
     def run(self, rec, x, first=None):
-        x = rec.conv_bn(x, first if first is not None else self.conv[0], self.conv[1], relu=True)
+        x = rec.conv_bn(x, first if first is not None else self.conv[0], self.conv[1], relu=True, split_for=self.conv[3])
         return rec.conv_bn(x, self.conv[3], self.conv[4], relu=True)
 
 
@@ -579,7 +579,7 @@ class BasicBlock(nn.Module):
 
     def run(self, rec, x):
         r = x if self.downsample is None else rec.conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        y = rec.conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = rec.conv_bn(x, self.conv1, self.bn1, relu=True, split_for=self.conv2)        # (conv2 is y's only reader)
         return rec.conv_bn(y, self.conv2, self.bn2, relu=True, residual=r)
 
 
@@ -597,7 +597,7 @@ class Bottleneck(nn.Module):
 
     def run(self, rec, x):
         r = x if self.downsample is None else rec.conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        y = rec.conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = rec.conv_bn(x, self.conv1, self.bn1, relu=True, split_for=self.conv2)
         y = rec.conv_bn(y, self.conv2, self.bn2, relu=True)
         return rec.conv_bn(y, self.conv3, self.bn3, relu=True, residual=r)
 
@@ -688,7 +688,7 @@ class HighResolutionModule(nn.Module):
         for kblk in range(depth):
             blks = [self.branches[b][kblk] for b in range(nb)]
             ys = rec.conv_bn_group([(xs[b], blks[b].conv1, blks[b].bn1, None) for b in range(nb)], relu=True,
-                                   single_reader=True)
+                                   single_reader=True, split_for=[blks[b].conv2 for b in range(nb)])
             xs = rec.conv_bn_group([(ys[b], blks[b].conv2, blks[b].bn2, xs[b]) for b in range(nb)], relu=True)
         return xs
 

@@ -32,7 +32,7 @@ _f = C.c_float
 class ConvShape(C.Structure):
     """hrseg_conv_shape_t"""
     _fields_ = [(n, _i) for n in ("B", "Hi", "Wi", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "ksize", "stride", "precision")] + \
-               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i), ("stat_partial", _p), ("stat_rows", C.POINTER(C.c_int)), ("w_persistent", _i)]
+               [("grad_absmax", _p), ("residual", _p), ("ldr", _i), ("relu", _i), ("stat_partial", _p), ("stat_rows", C.POINTER(C.c_int)), ("x_split", _i), ("w_persistent", _i)]
 
 
 # hrseg_conv_precision (include/hrseg.h): arithmetic of the convolution contractions
@@ -44,7 +44,7 @@ class BnFwd(C.Structure):
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
                 ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
-                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("stat_ranks", _i)]
+                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("z_split", _i), ("stat_ranks", _i)]
 
 
 class BnBwd(C.Structure):
@@ -129,6 +129,15 @@ _lib.hrseg_last_error_string.restype = C.c_char_p
 _lib.hrseg_last_error_string.argtypes = []
 _lib.hrseg_abi_version.restype = _i
 _lib.hrseg_abi_version.argtypes = []
+
+_lib.hrseg_conv_x_split_ok.restype = _i
+_lib.hrseg_conv_x_split_ok.argtypes = [_i, C.POINTER(ConvShape)]
+
+
+def conv_x_split_ok(shapes, n=None) -> bool:
+    """may the producer of these convolutions' inputs store them pre-split (hrseg_conv_x_split_ok)?"""
+    return bool(_lib.hrseg_conv_x_split_ok(len(shapes) if n is None else n, shapes))
+
 
 _lib.hrseg_conv_wgrad_workspace_bytes.restype = C.c_size_t
 _lib.hrseg_conv_wgrad_workspace_bytes.argtypes = [_i, C.POINTER(ConvShape)]
@@ -238,7 +247,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 13    # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 14    # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

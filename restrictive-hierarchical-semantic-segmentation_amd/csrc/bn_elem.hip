@@ -849,7 +849,11 @@ __global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
     }
-    st4(p.z + pix * p.ldz + 4 * L.cq, v);
+    // z_split: the tensor's only readers are fp16x2 convolutions that take their pixel operand pre-split (hrseg_conv_shape_t.
+    // x_split): the granule goes out as {hi01, hi23, lo01, lo23} -- the same 16 bytes per 4 channels, the split done once here
+    // (a bandwidth-bound kernel with VALU to spare) instead of by every staging wave of the readers
+    if (p.z_split) *reinterpret_cast<hrseg_u32x4*>(p.z + pix * p.ldz + 4 * L.cq) = hrseg_split_f16x2(v);
+    else st4(p.z + pix * p.ldz + 4 * L.cq, v);
   }
 }
 

@@ -7,6 +7,21 @@
 #include "../../include/hrseg.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hrseg_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hrseg_f16x2 __attribute__((ext_vector_type(2)));
+#ifdef __HIPCC__
+// One fp32 granule (4 channels of a pixel) in PRE-SPLIT fp16x2 form: dwords {hi01, hi23, lo01, lo23} with hi = round-toward-zero
+// fp16 of x and lo = round-to-nearest fp16 of (x - hi) -- exactly what conv_sp.h sp_split4<4> produces on the fly (scale 1), so a
+// convolution that reads a tensor stored this way multiplies the same bits as one that splits the fp32 tensor itself.
+__device__ __forceinline__ hrseg_u32x4 hrseg_split_f16x2(const f32x4& x) {
+  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2], x[3]));
+  const hrseg_f16x2 a = __builtin_bit_cast(hrseg_f16x2, h0), b = __builtin_bit_cast(hrseg_f16x2, h1);
+  const hrseg_f16x2 l0 = {(_Float16)(x[0] - (float)a[0]), (_Float16)(x[1] - (float)a[1])};
+  const hrseg_f16x2 l1 = {(_Float16)(x[2] - (float)b[0]), (_Float16)(x[3] - (float)b[1])};
+  return hrseg_u32x4{h0, h1, __builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+}
+#endif
 
 #define HRSEG_WAVE 64
 

@@ -399,6 +399,7 @@ static bool ws_make_images(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   if (g.n) launch_weight_images(g, end, st);
   return true;
 }
+static int g_exp_nosplit = 0;           // hrseg_tune "exp_nosplit_x": MEASUREMENT ONLY -- the ceiling of "activations pre-split in HBM" (results wrong)
 static int g_ws_epi_early = 1;          // hrseg_tune "ws_epi_early": 0 = the wave-specialised body reads accumulate / residual values at the tile's end
 // hrseg_tune "ws_epi_cost" / "ws_epi_acc_cost": what a tile costs beyond its slabs, in slab times (0 = the defaults below,
 // negative = none), for the block partition of a grouped launch.  A tile's prologue / epilogue (tile switch, 12 KB of stores per
@@ -409,7 +410,9 @@ static int g_ws_epi_early = 1;          // hrseg_tune "ws_epi_early": 0 = the wa
 static int g_ws_epi_cost = 0, g_ws_epi_acc_cost = 0;
 static const int WS_EPI_COST = 10, WS_EPI_ACC_COST = 16;
 static int launch_ws_single(IgemmArgs a, int kind, hipStream_t st, int ns = 4) {
+  if (a.x_presplit && ns != 4) return 1;                   // (the caller refuses the route: the pre-split form is fp16x2's)
   a.epi_early = g_ws_epi_early;
+  a.exp_nosplit = (g_exp_nosplit && !patch_flip(a)) ? 1 : 0;      // (forward only: the data gradient's operand is a scaled gradient)
   ws_set_canvas(a, kind);
   const int ntotal = (int)ws_tiles(a, kind);
   if (!ws_make_images(&a, &kind, 1, st, ns)) return 1;
@@ -429,6 +432,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
   long cost[MAXG], ntot[MAXG], total = 0;
   int blocks[MAXG], flip = -1;
   for (int i = 0; i < n; ++i) {
+    if (a[i].x_presplit && ns != 4) return 1;
     const int f = patch_flip(a[i]);
     if (flip >= 0 && f != flip) return 1;
     flip = f;
@@ -436,6 +440,7 @@ static int launch_ws_group(IgemmArgs* a, const int* kinds, int n, hipStream_t st
     ws_set_canvas(a[i], kinds[i]);
     ntot[i] = ws_tiles(a[i], kinds[i]);
     a[i].epi_early = g_ws_epi_early;
+    a[i].exp_nosplit = (g_exp_nosplit && !f) ? 1 : 0;
     // slabs per tile, plus the tile's epilogue in slab times (an accumulating / residual epilogue waits for its reads)
     const int ec = g_ws_epi_cost ? (g_ws_epi_cost > 0 ? g_ws_epi_cost : 0) : WS_EPI_COST;
     const int eac = g_ws_epi_acc_cost ? (g_ws_epi_acc_cost > 0 ? g_ws_epi_acc_cost : 0) : WS_EPI_ACC_COST;
@@ -546,6 +551,12 @@ static int resolve_auto(const IgemmArgs& a, int precision) {
   return (k && ws_tiles(a, k) >= g_ws_min_tiles) ? HRSEG_CONV_FP16X2 : HRSEG_CONV_F32;
 }
 
+// a pre-split pixel operand (hrseg_conv_shape_t.x_split) is readable by the wave-specialised forward kernels and the nine-tap
+// weight gradient only: every other route refuses it loudly instead of reading the bytes as fp32
+static int x_split_unsupported(const char* who) {
+  hrseg_set_error("%s: x_split is set but this problem does not run the wave-specialised / nine-tap kernels (ask hrseg_conv_x_split_ok first)", who);
+  return HRSEG_ERR_UNSUPPORTED;
+}
 static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) {
   IgemmArgs a = a_in;
   if (int e = finalize_args(a)) return e;
@@ -556,6 +567,7 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
       const int kind = ws_kind(a);
       if (kind && ws_tiles(a, kind) >= g_ws_min_tiles && launch_ws_single(a, kind, st, ns) == 0) return 0;
     }
+    if (a.x_presplit) return x_split_unsupported("hrseg_conv_fwd");
     if (const int cs = patch_cs(a, pl.wtn)) {
       const int rc = launch_patch_sp(ns, a, pl.wtn, cs, st);
       if (rc == 0) return 0;
@@ -574,6 +586,7 @@ static int dispatch_igemm(const IgemmArgs& a_in, int precision, hipStream_t st) 
     if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
     return launch_sp(ns, a, pl, st);
   }
+  if (a.x_presplit) return x_split_unsupported("hrseg_conv_fwd");
   IgemmPlan pl = plan_igemm(a);
   if (pl.ksplit > 1 && !a.accumulate) zero_f32(a.y, (size_t)a.B * a.Hy * a.Wy * a.N, st);
   if (launch_igemm_f32(a, pl, st) == 0) { ++g_cnt[CNT_F32]; return 0; }
@@ -638,6 +651,9 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
       IgemmArgs f = rest[0];
       pair = finalize_args(f) == 0 && f.N % 48 == 0 && patch_cs(f, 3) == 3;
     }
+    bool split_rest = false;
+    for (int i = 0; i < nr; ++i) split_rest = split_rest || rest[i].x_presplit;
+    if (split_rest || (pair && (wsa[0].x_presplit))) return x_split_unsupported("hrseg_conv_fwd_group");
     if (nw >= 1 && !pair && launch_ws_group(wsa, kinds, nw, st) == 0) {
       if (nr == 0) return 0;
       if (nr == 1) { const int e = dispatch_igemm(rest[0], HRSEG_CONV_AUTO, st); return e < 0 ? e : (e ? HRSEG_ERR_LAUNCH : 0); }
@@ -647,6 +663,8 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
       return 0;
     }
   }
+  for (int i = 0; i < n; ++i)
+    if (a[i].x_presplit) return x_split_unsupported("hrseg_conv_fwd_group");
   IgemmArgs hi[MAXG], lo[MAXG];
   int nh = 0, nl = 0;
   for (int i = 0; i < n; ++i) {
@@ -682,6 +700,8 @@ static int dispatch_igemm_group_auto(const IgemmArgs* a, int n, hipStream_t st, 
 static int dispatch_igemm_group(const IgemmArgs* a, int n, int precision, hipStream_t st) {
   if (n < 2 || n > MAXG || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 1;
   if (precision == HRSEG_CONV_AUTO) return dispatch_igemm_group_auto(a, n, st);
+  for (int i = 0; i < n; ++i)
+    if (a[i].x_presplit) return x_split_unsupported("hrseg_conv_fwd_group");
   const int ns = sp_pieces(precision);
   if (ns == 1 && g_ws_bf16 && g_sp_ws && scratch_usable() && !g_sp_wtn) {
     // bf16 arithmetic (BASELINE configs[4]): the problems the wave-specialised body takes go out as one launch of its
@@ -928,6 +948,8 @@ static size_t wgrad9_ws_bytes(int n, const hrseg_conv_shape_t* shapes) {
 static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy, float* const* dw,
                            const hrseg_conv_shape_t* shapes, float* ws, hipStream_t st) {
   const int ns = sp_pieces(shapes[0].precision);
+  for (int i = 0; i < n; ++i)
+    if (shapes[i].x_split && ns != 4) return x_split_unsupported("hrseg_conv_wgrad_group_ws");
   Wg9Plan pl;
   if (!wgrad9_plan_all(n, shapes, pl)) return HRSEG_ERR_UNSUPPORTED;      // (the caller asked wgrad9_ws_bytes first)
   const int tnk = pl.tnk;
@@ -938,6 +960,8 @@ static int dispatch_wgrad9(int n, const float* const* x, const float* const* dy,
   for (int i = 0; i < n; ++i) {
     Wgrad9Args& a = pl.a[i];
     a.x = x[i]; a.dy = dy[i]; a.ws = ws;
+    a.exp_nosplit = g_exp_nosplit;
+    a.x_presplit = shapes[i].x_split;
     a.dymax = shapes[i].precision == HRSEG_CONV_FP16X2 ? shapes[i].grad_absmax : nullptr;
     HRSEG_CHECK_ARG((double)shapes[i].Hi * shapes[i].Wi * (double)(shapes[i].ldx > shapes[i].ldy ? shapes[i].ldx : shapes[i].ldy) * 4.0 < 4294967296.0,
                     "wgrad9: one image exceeds the 4 GB buffer-offset range");
@@ -1037,6 +1061,7 @@ static void fill_fwd_args(IgemmArgs& a, const float* x, const float* w, const fl
   set_sp_scales(a, s->precision, nullptr);
   a.res = s->residual; a.ldr = s->ldr; a.relu = s->relu;
   a.w_persistent = s->w_persistent;
+  a.x_presplit = s->x_split;
   // BatchNorm statistics in the epilogue: offered to the launchers only where the caller gave both pointers, the output is the
   // BatchNorm's input as stored (no fused residual / ReLU) and the run need not be bit-reproducible
   if (s->stat_partial && s->stat_rows) {
@@ -1139,6 +1164,8 @@ extern "C" int hrseg_conv_dgrad_group(int n, const float* const* dy, const float
 extern "C" int hrseg_conv_wgrad_group(int n, const float* const* x, const float* const* dy, float* const* dw,
                                       const hrseg_conv_shape_t* shapes, hrseg_stream_t stream) {
   HRSEG_CHECK_ARG(n >= 1 && x && dy && dw && shapes, "hrseg_conv_wgrad_group: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (shapes[i].x_split) return x_split_unsupported("hrseg_conv_wgrad_group");
   hipStream_t st = (hipStream_t)stream;
   bool ok = n <= MAXG;
   for (int i = 0; i < n; ++i) {
@@ -1171,6 +1198,32 @@ extern "C" size_t hrseg_conv_wgrad_workspace_bytes(int n, const hrseg_conv_shape
   for (int i = 0; i < n; ++i)
     if (check_shape(&shapes[i], "hrseg_conv_wgrad_workspace_bytes")) return 0;
   return wgrad9_ws_bytes(n, shapes);
+}
+
+static int g_x_split = 1;              // hrseg_tune "x_split": 0 = hrseg_conv_x_split_ok always answers no (activations stay fp32 everywhere)
+// Mirrors the routing of hrseg_conv_fwd(_group) and hrseg_conv_wgrad_group_ws for these shapes: yes only when EVERY problem of
+// the forward call goes out through the wave-specialised kernels (fp16x2 arithmetic) and the weight gradients through the
+// nine-tap kernel.  The calls themselves refuse x_split on any other route, so a mismatch is an error, never a misread tensor.
+extern "C" int hrseg_conv_x_split_ok(int n, const hrseg_conv_shape_t* shapes) {
+  if (!g_x_split || !shapes || n < 1 || n > MAXG || n > WG9_MAXG) return 0;
+  if (!g_sp_ws || !scratch_usable() || g_sp_wtn || g_tune_wtm || g_tune_kc || g_tune_db || g_tune_ksplit) return 0;
+  for (int i = 0; i < n; ++i) {
+    const hrseg_conv_shape_t& s = shapes[i];
+    if (s.ksize != 3 || s.stride != 1 || s.residual || s.relu || !mfma_shape(&s) || s.precision != shapes[0].precision) return 0;
+    if (s.precision != HRSEG_CONV_AUTO && !(s.precision == HRSEG_CONV_FP16X2 && n == 1)) return 0;      // (explicit fp16x2 GROUPS run the block-synchronous kernels)
+    if (s.B < 1 || s.Hi < 1 || s.Wi < 1 || s.Ho != s.Hi || s.Wo != s.Wi) return 0;
+    IgemmArgs a;
+    fill_fwd_args(a, reinterpret_cast<const float*>(256), reinterpret_cast<const float*>(256), nullptr, reinterpret_cast<float*>(256), &s);
+    a.stat_partial = nullptr; a.stat_rows = nullptr;
+    if (finalize_args(a)) return 0;
+    const int k = ws_kind(a);
+    if (!k || ws_tiles(a, k) < g_ws_min_tiles) return 0;
+  }
+  hrseg_conv_shape_t rs[WG9_MAXG];
+  resolve_wgrad_shapes(n, shapes, rs);
+  for (int i = 0; i < n; ++i)
+    if (sp_pieces(rs[i].precision) != 4) return 0;
+  return wgrad9_ws_bytes(n, rs) > 0 ? 1 : 0;
 }
 
 extern "C" int hrseg_conv_wgrad_group_ws(int n, const float* const* x, const float* const* dy, float* const* dw,
@@ -1284,6 +1337,7 @@ extern "C" int hrseg_conv_dgrad(const float* dy, const float* wt, float* dx, int
 
 extern "C" int hrseg_conv_wgrad(const float* x, const float* dy, float* dw, const hrseg_conv_shape_t* s_in,
                                 hrseg_stream_t stream) {
+  if (s_in && s_in->x_split) return x_split_unsupported("hrseg_conv_wgrad");
   HRSEG_CHECK_ARG(s_in != nullptr, "hrseg_conv_wgrad: null shape");
   hrseg_conv_shape_t sh;
   resolve_wgrad_shapes(1, s_in, &sh);
@@ -1368,7 +1422,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"ws_epi_early", &g_ws_epi_early}, {"ws_epi_cost", &g_ws_epi_cost}, {"ws_epi_acc_cost", &g_ws_epi_acc_cost}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"ws_epi_early", &g_ws_epi_early}, {"exp_nosplit_x", &g_exp_nosplit}, {"x_split", &g_x_split}, {"ws_epi_cost", &g_ws_epi_cost}, {"ws_epi_acc_cost", &g_ws_epi_acc_cost}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

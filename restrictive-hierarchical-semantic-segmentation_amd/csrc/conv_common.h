@@ -37,6 +37,8 @@ struct IgemmArgs {
   double* stat_partial;      // wave-specialised body, forward: BatchNorm partial sums of the output, one row [2][N] per block (else null)
   int* stat_rows;            // HOST pointer: the launcher writes the number of rows (blocks) there; not read by any kernel
   int w_persistent;          // w is a parameter the caller keeps images of up to date (hrseg_weight_images_refresh): see conv.hip
+  int exp_nosplit;           // MEASUREMENT ONLY (hrseg_tune exp_nosplit_x): the wave-specialised producers stage x without splitting it
+  int x_presplit;            // x is stored pre-split (hrseg_conv_shape_t.x_split): only the wave-specialised forward body reads that form
 };
 
 // exact n / d for 0 <= n < 2^24 via the float reciprocal (+-1 correction); rcp <= 0 (set by the host for

@@ -1874,9 +1874,16 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       const unsigned off = ok ? (unsigned)((bc * H + iy) * W + ix) * ldx4 + prem16 : HRSEG_BUF_OOB;
       ld16(dst, rx, off, ks * CS * 64);
     };
+    const int exp_nosplit = p.exp_nosplit | p.x_presplit;        // x stored pre-split: copy, do not split (see hrseg.h x_split)
     auto patch_store1 = [&](const f32x4& v, int i, int pbuf) {
       u32x2 pc[sp_np(NS)];
-      sp_split4<NS>(v, pc, xscale);
+      if (exp_nosplit) {                           // MEASUREMENT ONLY (hrseg_tune exp_nosplit_x; wrong values on purpose)
+        const u32x4 raw = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int s = 0; s < sp_np(NS); ++s) pc[s] = u32x2{raw[(2 * s) & 3], raw[(2 * s + 1) & 3]};
+      } else {
+        sp_split4<NS>(v, pc, xscale);
+      }
       const int pix = pix0 + PR * i;
       const int o = pbuf * L::PATCH + pst0 + pix * 32 + ((pq ^ (2 * ((pix >> 3) & 1))) << 3);
       if (pwork & (pix < PP)) {
@@ -2057,6 +2064,8 @@ struct Wgrad9Args {
   const float* dymax;                              // device scalar |dy|_max (fp16x2 scaling) or null
   int ldx, lddy, B, H, W, Cin, Cout;
   int tiles_x, tiles_y, ntiles, nchunks, per;      // per = tiles per chunk
+  int exp_nosplit;                                 // MEASUREMENT ONLY (hrseg_tune exp_nosplit_x): stage x as if it came pre-split
+  int x_presplit;                                  // x is stored pre-split (hrseg_conv_shape_t.x_split)
 };
 
 template <int NS, int TNK>
@@ -2112,7 +2121,14 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       u32x2 pc[sp_np(NS)];
-      sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
+      if (i >= DY_LOADS && (p.x_presplit | p.exp_nosplit)) {      // x stored pre-split (hrseg_conv_shape_t.x_split): the 16 bytes ARE {hi01, hi23, lo01, lo23}
+        // (exp_nosplit: the same copy on fp32 data, wrong values on purpose: the ceiling measurement of tools/)
+        const u32x4 raw = __builtin_bit_cast(u32x4, rg[i]);
+#pragma unroll
+        for (int s = 0; s < sp_np(NS); ++s) pc[s] = u32x2{raw[(2 * s) & 3], raw[(2 * s + 1) & 3]};
+      } else {
+        sp_split4<NS>(rg[i], pc, i < DY_LOADS ? dyscale : 1.f);
+      }
       const int pix = (i < DY_LOADS) ? pix0 + PR * i : L::DYPIX + pix0 + PR * (i - DY_LOADS);
       const int o = pix * S + gq * 8;
       if (swork && (i < DY_LOADS ? pix < L::DYPIX : pix < L::DYPIX + L::XPIX)) {

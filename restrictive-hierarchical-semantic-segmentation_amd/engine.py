@@ -39,6 +39,7 @@ _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the back
 #   skip_wgrad:  no weight-gradient launch at all = what the side stream's work costs the step beside the main chain
 _EXPERIMENT = set(filter(None, os.environ.get("HRSEG_EXPERIMENT", "").split(",")))
 _CONV_STATS = os.environ.get("HRSEG_CONV_STATS", "1") != "0"       # 0: BatchNorm statistics always as their own launch
+_X_SPLIT = os.environ.get("HRSEG_X_SPLIT", "1") != "0"             # 0: activations are fp32 everywhere (no pre-split tensors)
 
 
 def wgrad_stream(device):
@@ -54,13 +55,15 @@ def wgrad_stream(device):
 
 
 class Act:
-    """An activation and its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "slot")
+    """An activation and its gradient slot.  `split`: the tensor is stored pre-split for fp16x2 convolutions (per 4 channels
+    {hi01, hi23, lo01, lo23}, include/hrseg.h x_split) -- only convolutions read it, through conv_bn_group"""
+    __slots__ = ("data", "grad", "needs_grad", "slot", "split")
 
-    def __init__(self, data, needs_grad=True):
+    def __init__(self, data, needs_grad=True, split=False):
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        self.split = split
 
     @property
     def shape(self):
@@ -234,10 +237,15 @@ class Recorder:
         act.grad = g
 
     # ------------------------------------------------------------------ conv + BN (+residual) (+ReLU)
-    def conv_bn(self, x, conv, bn, relu, residual=None, out=None):
-        return self.conv_bn_group([(x, conv, bn, residual)], relu, outs=[out])[0]
+    def conv_bn(self, x, conv, bn, relu, residual=None, out=None, split_for=None):
+        return self.conv_bn_group([(x, conv, bn, residual)], relu, outs=[out],
+                                  split_for=[split_for] if split_for is not None else None)[0]
 
-    def conv_bn_group(self, items, relu, outs=None, single_reader=False):
+    def conv_bn_group(self, items, relu, outs=None, single_reader=False, split_for=None):
+        """... split_for: one convolution per item that is the ONLY reader of that item's output (conv1 -> conv2 of a block).
+        Where the library will run those readers on the kernels that take a pre-split pixel operand (hrseg_conv_x_split_ok:
+        wave-specialised forward + nine-tap weight gradient, fp16x2 arithmetic) the BatchNorm apply writes the output
+        pre-split -- the same bytes the readers' staging waves would compute from the fp32 tensor, computed once."""
         """items: list of (x, conv, bn, residual-or-None), independent of each other (the parallel
         HRNet branches, the fuse paths of a module; a single layer is a group of one); relu: one flag or
         one per item.  Per group: one conv launch, three BN launches; backward: three BN launches, one
@@ -270,7 +278,8 @@ class Recorder:
         if n == 1:
             conv = items[0][1]
             ys = ops.conv_fwd(xs[0].data, conv.weight._hr_store, conv.bias._hr_store if conv.bias is not None else None,
-                              k, s, cout=conv.out_channels, prec=self.prec, stats=want_stats, wpersist=self.wpersist)
+                              k, s, cout=conv.out_channels, prec=self.prec, stats=want_stats, wpersist=self.wpersist,
+                              x_split=xs[0].split)
             if want_stats:
                 ys, st = ys
                 stats = [st]
@@ -279,7 +288,7 @@ class Recorder:
             ys = ops.conv_fwd_group([x.data for x in xs], [c.weight._hr_store for _, c, _, _ in items],
                                     [c.bias._hr_store if c.bias is not None else None for _, c, _, _ in items], k, s,
                                     [c.out_channels for _, c, _, _ in items], prec=self.prec, stats=want_stats,
-                                    wpersist=self.wpersist)
+                                    wpersist=self.wpersist, x_splits=[x.split for x in xs])
             if want_stats:
                 ys, stats = ys
         if stats is not None and any(st is None for st in stats):
@@ -289,11 +298,17 @@ class Recorder:
         masks = [torch.empty((y.shape[0] * y.shape[1] * y.shape[2], y.shape[3] // 4), dtype=torch.uint8, device=y.device)
                  if (self.record and _RELU_MASK and relus[i] and it[3] is not None) else None
                  for i, (it, y) in enumerate(zip(items, ys))]
+        z_split = False
+        if split_for is not None and _X_SPLIT and not _EXPERIMENT and (outs is None or all(o is None for o in outs)) \
+                and all(c is not None for c in split_for):
+            k2, s2 = split_for[0].kernel_size[0], split_for[0].stride[0]
+            if all(c.kernel_size[0] == k2 and c.stride[0] == s2 for c in split_for):
+                z_split = ops.conv_x_split_ok([tuple(y.shape) for y in ys], [c.out_channels for c in split_for], k2, s2, self.prec)
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
                          residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
                          stat_div=self.bn_segments, relu_mask=masks[i],
-                         out=outs[i] if outs is not None else None,
+                         out=outs[i] if outs is not None else None, z_split=z_split,
                          partial=stats[i] if stats is not None else None)
                     for i, ((x, conv, bn, res), y) in enumerate(zip(items, ys))]
         if _EXPERIMENT and self.training and self.sync is None:
@@ -307,7 +322,7 @@ class Recorder:
                 zc = [(y, c) for y, (_, c) in zip(ys, zc)]
         else:
             zc = ops.bn_fwd_group(bn_items, self.training, sync=self.sync, phases=6 if stats is not None else 7)
-        zs = [Act(z) for z, _ in zc]
+        zs = [Act(z, split=z_split) for z, _ in zc]
         if not self.record:
             return zs
         coefs = [c for _, c in zc]
@@ -347,10 +362,11 @@ class Recorder:
                     _lib.stream_wait(side, None)
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                     if n == 1:
-                        ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0])
+                        ops.conv_wgrad(xs[0].data, dys[0], items[0][1].weight._hr_gstore, k, s, prec=self.prec, gmax=gmaxs[0],
+                                       x_split=xs[0].split)
                     else:
                         ops.conv_wgrad_group([x.data for x in xs], dys, [c.weight._hr_gstore for _, c, _, _ in items], k, s,
-                                             prec=self.prec, gmaxs=gmaxs)
+                                             prec=self.prec, gmaxs=gmaxs, x_splits=[x.split for x in xs])
                 if side is not None:
                     if _lib.taping():
                         # a recorded step is replayed without the allocator: what the side stream reads stays allocated

@@ -68,7 +68,8 @@ def conv_out_size(h, k, s):
     return (h + 2 * pad - k) // s + 1
 
 
-def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False, stat=None, wpersist=False):
+def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu=False, stat=None, wpersist=False,
+           x_split=False):
     """gmax: device scalar max|dy| of the gradient operand (fp16x2 data / weight gradients), see hrseg.h;
     residual / relu: the forward's fused epilogue y = relu?(conv + bias + residual) (inference with folded BatchNorm);
     stat: (device buffer of 256*2*Cout doubles, ctypes int) -- BatchNorm partial sums of the output from the epilogue"""
@@ -80,7 +81,15 @@ def _shape(x_shape, ldx, Cout, ldy, k, s, prec=0, gmax=None, residual=None, relu
         sh.stat_partial = ptr(stat[0])
         sh.stat_rows = C.pointer(stat[1])
     sh.w_persistent = int(bool(wpersist))
+    sh.x_split = int(bool(x_split))        # x is stored pre-split (bn_fwd_group item "z_split"): hrseg.h
     return sh
+
+
+def conv_x_split_ok(x_shapes, couts, k, s, prec):
+    """may the producer of these convolutions' inputs (NHWC shapes, contiguous) store them pre-split?  (hrseg_conv_x_split_ok:
+    every problem on the wave-specialised forward kernels and the nine-tap weight gradient)"""
+    shapes = _shape_array([_shape(tuple(xs), xs[3], co, co, k, s, prec) for xs, co in zip(x_shapes, couts)])
+    return _lib.conv_x_split_ok(shapes, len(x_shapes))
 
 
 STAT_ROWS_MAX = 256          # include/hrseg.h hrseg_conv_shape_t.stat_partial: rows the caller provides
@@ -120,19 +129,22 @@ def _guard_prec(x, prec):
 range_fallbacks = 0
 
 
-def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False, stats=False, wpersist=False):
+def conv_fwd(x, w, bias, k, s, out=None, cout=None, prec=0, residual=None, relu=False, stats=False, wpersist=False,
+             x_split=False):
     """x NHWC, w storage [Cout][k*k][Cin] (a channels_last [Cout,Cin,k,k] parameter);
     pass `cout` when w is the flat 1-D parameter slot.  `prec`: _lib.CONV_PRECISION code (all conv functions).
     stats=True: -> (out, (partial, rows) or None): the BatchNorm partial sums of the output where the kernel that ran
     produces them in its epilogue (hrseg_conv_shape_t.stat_partial), else None"""
     _lib.ensure_scratch(x.device)
-    prec = _guard_prec(x, prec)
+    if not x_split:                        # (a pre-split tensor is not fp32 data: its producer's fp32 values were in range)
+        prec = _guard_prec(x, prec)
     B, Hi, Wi, Cin = x.shape
     Cout = cout if cout is not None else w.shape[0]
     if out is None:
         out = empty_nhwc(B, conv_out_size(Hi, k, s), conv_out_size(Wi, k, s), Cout, x)
     st = _stat_buffer(Cout, x.device) if stats else None
-    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu, stat=st, wpersist=wpersist)
+    sh = _shape(x.shape, _ld(x), Cout, _ld(out), k, s, prec, residual=residual, relu=relu, stat=st, wpersist=wpersist,
+                x_split=x_split)
     call("hrseg_conv_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), C.byref(sh))
     if stats:
         return out, ((st[0], st[1].value) if st[1].value > 0 else None)
@@ -151,12 +163,13 @@ def conv_dgrad(dy, wt, x_shape, k, s, out=None, accumulate=False, prec=0, gmax=N
     return out
 
 
-def conv_wgrad(x, dy, dw, k, s, prec=0, gmax=None):
+def conv_wgrad(x, dy, dw, k, s, prec=0, gmax=None, x_split=False):
     """dw (+)= ; dw is the running gradient buffer [Cout][k*k][Cin]."""
-    prec = _guard_prec(x, prec)
+    if not x_split:
+        prec = _guard_prec(x, prec)
     if prec and k == 3 and s == 1:
-        return conv_wgrad_group([x], [dy], [dw], k, s, prec, [gmax])
-    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, gmax)
+        return conv_wgrad_group([x], [dy], [dw], k, s, prec, [gmax], x_splits=[x_split])
+    sh = _shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, gmax, x_split=x_split)
     call("hrseg_conv_wgrad", ptr(x), ptr(dy), ptr(dw), C.byref(sh))
 
 
@@ -164,11 +177,11 @@ def _shape_array(shapes):
     return (ConvShape * len(shapes))(*shapes)
 
 
-def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None, stats=False, wpersist=False):
+def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=None, stats=False, wpersist=False, x_splits=None):
     """n independent convolutions (same k, s) in one launch when the library can group them; residuals / relus: the fused
     epilogue per problem (inference with folded BatchNorm); stats=True: -> (outs, [(partial, rows) or None per problem])"""
     _lib.ensure_scratch(xs[0].device)
-    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
+    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for i, x in enumerate(xs) if not (x_splits and x_splits[i])):
         prec = _lib.CONV_PRECISION["f32"]        # (one precision per grouped call)
     outs, shapes, sts = [], [], []
     for i, (x, co) in enumerate(zip(xs, couts)):
@@ -177,7 +190,8 @@ def conv_fwd_group(xs, ws, biases, k, s, couts, prec=0, residuals=None, relus=No
         outs.append(y)
         sts.append(_stat_buffer(co, x.device) if stats else None)
         shapes.append(_shape(x.shape, _ld(x), co, _ld(y), k, s, prec, residual=residuals[i] if residuals is not None else None,
-                             relu=relus[i] if relus is not None else False, stat=sts[i], wpersist=wpersist))
+                             relu=relus[i] if relus is not None else False, stat=sts[i], wpersist=wpersist,
+                             x_split=bool(x_splits[i]) if x_splits else False))
     has_bias = any(b is not None for b in biases)
     call("hrseg_conv_fwd_group", len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws),
          _lib.ptr_array(biases) if has_bias else None, _lib.ptr_array(outs), _shape_array(shapes))
@@ -201,11 +215,13 @@ def conv_dgrad_group(dys, wts, x_shapes, k, s, outs, accumulate, prec=0, gmaxs=N
     return outs
 
 
-def conv_wgrad_group(xs, dys, dws, k, s, prec=0, gmaxs=None):
-    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for x in xs):
+def conv_wgrad_group(xs, dys, dws, k, s, prec=0, gmaxs=None, x_splits=None):
+    if _lib.deterministic() and any(_guard_prec(x, prec) != prec for i, x in enumerate(xs) if not (x_splits and x_splits[i])):
         prec = _lib.CONV_PRECISION["f32"]
     gm = gmaxs if gmaxs is not None else [None] * len(xs)
-    shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, g) for x, dy, g in zip(xs, dys, gm)])
+    sp = x_splits if x_splits else [False] * len(xs)
+    shapes = _shape_array([_shape(x.shape, _ld(x), dy.shape[3], _ld(dy), k, s, prec, g, x_split=bool(q))
+                           for x, dy, g, q in zip(xs, dys, gm, sp)])
     nbytes = _lib.conv_wgrad_workspace_bytes(shapes, len(xs)) if (prec and k == 3 and s == 1) else 0
     if nbytes:
         # split-precision 3x3 stride-1 problems: per-block partial sums in a workspace + ordered reduce (no atomics)
@@ -346,6 +362,7 @@ def bn_fwd_group(items, training, sync=None, phases=7):
         a.residual, a.ldr, a.relu = ptr(res), (_ld(res) if res is not None else 0), int(it["relu"])
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         a.relu_mask = ptr(it.get("relu_mask"))
+        a.z_split = int(bool(it.get("z_split", False)))
         a.stat_ranks = ranks
         if training and it.get("partial") is not None:
             part, nch = it["partial"]                   # partial sums left by the convolution's epilogue (phases 6)

@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_prototypes_match():
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} declared in hrseg.h but not exported"
         if name in ("hrseg_last_error_string", "hrseg_abi_version", "hrseg_tune", "hrseg_conv_wgrad_workspace_bytes",
-                    "hrseg_launch_count"):
+                    "hrseg_launch_count", "hrseg_conv_x_split_ok"):
             continue
         protos = _lib.RAW_PROTOTYPES if name in _lib.RAW_PROTOTYPES else _lib.PROTOTYPES
         assert name in protos, f"{name} has no ctypes prototype"
@@ -44,7 +44,7 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == _lib.ABI_VERSION == 13
+    assert _lib.abi_version() == _lib.ABI_VERSION == 14
     assert not any(n.startswith("hrseg_debug_") for n in decls), "experimental switches do not belong in the public header"
 
 

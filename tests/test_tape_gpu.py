@@ -214,3 +214,38 @@ def test_cached_weight_images_follow_the_weights(name, monkeypatch):
         assert abs(base[0][0] - base[0][2]) > 1e-3 * abs(base[0][0])       # the steps did move the loss
     finally:
         _lib.set_deterministic(False)
+
+
+@pytest.mark.parametrize("name", ["hrnet_hier_tl_64", "unet_hier_tl_62"])
+def test_presplit_single_reader_activations_change_no_bit(name, monkeypatch):
+    """conv1 -> conv2 of a block: where the library runs conv2 on the kernels that take a pre-split pixel operand, BatchNorm
+    writes conv1's activation pre-split (hrseg_bn_fwd_t.z_split / hrseg_conv_shape_t.x_split) -- the bytes conv2's staging
+    would compute from the fp32 tensor.  Three train steps with and without (engine._X_SPLIT), deterministic mode: same bits."""
+    from hrseg_amd import _lib, engine, train as PT
+    from tests.helpers import conv_mode
+    _lib.set_deterministic(True)
+    try:
+        res = {}
+        for on in (True, False):
+            monkeypatch.setattr(engine, "_X_SPLIT", on)
+            model, opt, fns, args, tree, g = _setup(name, lr=1e-2)
+            split_calls = []
+            orig = engine.ops.bn_fwd_group
+
+            def spy(items, *a, **k):
+                split_calls.append(any(it.get("z_split") for it in items))
+                return orig(items, *a, **k)
+            monkeypatch.setattr(engine.ops, "bn_fwd_group", spy)
+            losses = []
+            with conv_mode(model, "auto_ws"):
+                for x, t in _batches(g, 3):
+                    losses.append(float(PT.train_step(model, opt, x, t, fns, args, tree, [])[0]))
+                torch.cuda.synchronize()
+            monkeypatch.setattr(engine.ops, "bn_fwd_group", orig)
+            assert any(split_calls) == on, (on, sum(split_calls))
+            res[on] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+        for k, v in res[False][1].items():
+            assert torch.equal(res[True][1][k], v), k
+    finally:
+        _lib.set_deterministic(False)
