@@ -256,6 +256,9 @@ typedef struct {
   int z_split;                                       /* != 0: z is written PRE-SPLIT for fp16x2 convolutions (per 4
                                                         channels {hi01, hi23, lo01, lo23}, same 16 bytes): only for a
                                                         tensor whose every reader takes hrseg_conv_shape_t.x_split */
+  int residual_split;                                /* != 0: `residual` is stored pre-split (z_split of the launch that
+                                                        wrote it); the apply phase adds hi + lo, i.e. the fp32 value
+                                                        rounded to the 22 bits the convolutions multiply            */
   int stat_ranks;                                    /* cross-rank statistics (opt-in synchronised BN): the
                                                         partial sums were all-reduced over this many ranks of
                                                         equal shards between the statistics and the finalize

@@ -689,7 +689,11 @@ class HighResolutionModule(nn.Module):
             blks = [self.branches[b][kblk] for b in range(nb)]
             ys = rec.conv_bn_group([(xs[b], blks[b].conv1, blks[b].bn1, None) for b in range(nb)], relu=True,
                                    single_reader=True, split_for=[blks[b].conv2 for b in range(nb)])
-            xs = rec.conv_bn_group([(ys[b], blks[b].conv2, blks[b].bn2, xs[b]) for b in range(nb)], relu=True)
+            # a block's output is read by the next block of the branch only (its conv1, and its BatchNorm apply as the
+            # residual: residual_split) -- except the last block's, which the fuse layers read as fp32
+            nxt = [self.branches[b][kblk + 1].conv1 for b in range(nb)] if kblk + 1 < depth else None
+            xs = rec.conv_bn_group([(ys[b], blks[b].conv2, blks[b].bn2, xs[b]) for b in range(nb)], relu=True, split_for=nxt,
+                                   split_level=2)
         return xs
 
     def run(self, rec, xs):

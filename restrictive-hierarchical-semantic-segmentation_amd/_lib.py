@@ -44,7 +44,7 @@ class BnFwd(C.Structure):
     _fields_ = [("y", _p), ("ldy", _i), ("npix", _l), ("C", _i), ("gamma", _p), ("beta", _p), ("running_mean", _p),
                 ("running_var", _p), ("num_batches_tracked", _p), ("momentum", _f), ("eps", _f), ("residual", _p),
                 ("ldr", _i), ("relu", _i), ("z", _p), ("ldz", _i), ("coef", _p), ("partial", _p), ("nchunks", _i),
-                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("z_split", _i), ("stat_ranks", _i)]
+                ("stat_div", _i), ("stat_updates", _i), ("relu_mask", _p), ("z_split", _i), ("residual_split", _i), ("stat_ranks", _i)]
 
 
 class BnBwd(C.Structure):
@@ -247,7 +247,7 @@ for _name, _args in PROTOTYPES.items():
     _fn[_name] = f
 
 
-ABI_VERSION = 14    # must equal hrseg_abi_version() of the built library (struct layouts above)
+ABI_VERSION = 15    # must equal hrseg_abi_version() of the built library (struct layouts above)
 
 
 raw = {}

@@ -841,7 +841,10 @@ __global__ __launch_bounds__(256) void bn_apply_group_kernel(BnFwdG g) {
   const f32x4 sc = ld4(p.coef + 2 * C + 4 * L.cq), sh = ld4(p.coef + 3 * C + 4 * L.cq);
   for (long pix = (long)local * L.P + L.pl; pix < p.npix; pix += (long)nblk * L.P) {
     f32x4 v = bn_affine(ld4(p.y + pix * p.ldy + 4 * L.cq), sc, sh);
-    if (p.residual) v += ld4(p.residual + pix * p.ldr + 4 * L.cq);
+    if (p.residual) {       // (residual_split: the block input is stored pre-split for its convolution readers; hi + lo is its value)
+      const float* r = p.residual + pix * p.ldr + 4 * L.cq;
+      v += p.residual_split ? hrseg_join_f16x2(*reinterpret_cast<const hrseg_u32x4*>(r)) : ld4(r);
+    }
     if (p.relu) {
       // one byte per (pixel, channel quad): bit j = "channel 4q+j passed the ReLU".  With a residual the backward cannot
       // recompute the mask from y alone; reading this byte instead of z saves it 4 B per element, twice

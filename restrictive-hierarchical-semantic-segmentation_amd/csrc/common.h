@@ -21,6 +21,17 @@ __device__ __forceinline__ hrseg_u32x4 hrseg_split_f16x2(const f32x4& x) {
   const hrseg_f16x2 l1 = {(_Float16)(x[2] - (float)b[0]), (_Float16)(x[3] - (float)b[1])};
   return hrseg_u32x4{h0, h1, __builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
 }
+// ... and back: hi + lo (exact in fp32: the value the convolutions multiply, the fp32 original rounded to 22 bits)
+__device__ __forceinline__ float hrseg_h2f(unsigned bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); }
+__device__ __forceinline__ f32x4 hrseg_join_f16x2(const hrseg_u32x4& g) {
+  const unsigned h01 = g[0], h23 = g[1], l01 = g[2], l23 = g[3];
+  f32x4 r;
+  r[0] = hrseg_h2f(h01 & 0xffffu) + hrseg_h2f(l01 & 0xffffu);
+  r[1] = hrseg_h2f(h01 >> 16) + hrseg_h2f(l01 >> 16);
+  r[2] = hrseg_h2f(h23 & 0xffffu) + hrseg_h2f(l23 & 0xffffu);
+  r[3] = hrseg_h2f(h23 >> 16) + hrseg_h2f(l23 >> 16);
+  return r;
+}
 #endif
 
 #define HRSEG_WAVE 64

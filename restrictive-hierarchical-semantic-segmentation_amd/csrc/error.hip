@@ -15,4 +15,4 @@ void hrseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hrseg_last_error_string(void) { return g_err; }
-extern "C" int hrseg_abi_version(void) { return 14; }
+extern "C" int hrseg_abi_version(void) { return 15; }

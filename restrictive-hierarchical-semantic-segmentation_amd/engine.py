@@ -39,7 +39,10 @@ _RELU_MASK = os.environ.get("HRSEG_BN_RELU_MASK", "1") != "0"      # 0: the back
 #   skip_wgrad:  no weight-gradient launch at all = what the side stream's work costs the step beside the main chain
 _EXPERIMENT = set(filter(None, os.environ.get("HRSEG_EXPERIMENT", "").split(",")))
 _CONV_STATS = os.environ.get("HRSEG_CONV_STATS", "1") != "0"       # 0: BatchNorm statistics always as their own launch
-_X_SPLIT = os.environ.get("HRSEG_X_SPLIT", "1") != "0"             # 0: activations are fp32 everywhere (no pre-split tensors)
+# pre-split activations (include/hrseg.h x_split / z_split): 0 = fp32 everywhere; 1 = conv1 -> conv2 inside a block only (the
+# tensor has no other reader: results are bit-identical); 2 (default) = also a block's output where the next block of the branch
+# is its only reader -- that block's BatchNorm adds it as the residual in its 22-bit form (hi + lo), a 2^-23 relative rounding
+_X_SPLIT = int(os.environ.get("HRSEG_X_SPLIT", "2"))
 
 
 def wgrad_stream(device):
@@ -241,7 +244,7 @@ class Recorder:
         return self.conv_bn_group([(x, conv, bn, residual)], relu, outs=[out],
                                   split_for=[split_for] if split_for is not None else None)[0]
 
-    def conv_bn_group(self, items, relu, outs=None, single_reader=False, split_for=None):
+    def conv_bn_group(self, items, relu, outs=None, single_reader=False, split_for=None, split_level=1):
         """... split_for: one convolution per item that is the ONLY reader of that item's output (conv1 -> conv2 of a block).
         Where the library will run those readers on the kernels that take a pre-split pixel operand (hrseg_conv_x_split_ok:
         wave-specialised forward + nine-tap weight gradient, fp16x2 arithmetic) the BatchNorm apply writes the output
@@ -299,14 +302,18 @@ class Recorder:
                  if (self.record and _RELU_MASK and relus[i] and it[3] is not None) else None
                  for i, (it, y) in enumerate(zip(items, ys))]
         z_split = False
-        if split_for is not None and _X_SPLIT and not _EXPERIMENT and (outs is None or all(o is None for o in outs)) \
+        if split_for is not None and _X_SPLIT >= split_level and not _EXPERIMENT and (outs is None or all(o is None for o in outs)) \
                 and all(c is not None for c in split_for):
             k2, s2 = split_for[0].kernel_size[0], split_for[0].stride[0]
             if all(c.kernel_size[0] == k2 and c.stride[0] == s2 for c in split_for):
                 z_split = ops.conv_x_split_ok([tuple(y.shape) for y in ys], [c.out_channels for c in split_for], k2, s2, self.prec)
+                # (a layer with residual + ReLU hands its backward the mask bytes; without them the backward would read z as fp32)
+                z_split = z_split and all(m is not None or not (relus[i] and it[3] is not None)
+                                          for i, (it, m) in enumerate(zip(items, masks)))
         bn_items = [dict(y=y, gamma=bn.weight._hr_store, beta=bn.bias._hr_store, rm=bn.running_mean, rv=bn.running_var,
                          nbt=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps,
-                         residual=res.data if res is not None else None, relu=relus[i], repeat=self.bn_repeat,
+                         residual=res.data if res is not None else None, residual_split=bool(res is not None and res.split),
+                         relu=relus[i], repeat=self.bn_repeat,
                          stat_div=self.bn_segments, relu_mask=masks[i],
                          out=outs[i] if outs is not None else None, z_split=z_split,
                          partial=stats[i] if stats is not None else None)

@@ -363,6 +363,7 @@ def bn_fwd_group(items, training, sync=None, phases=7):
         a.z, a.ldz, a.coef = ptr(z), _ld(z), ptr(coef)
         a.relu_mask = ptr(it.get("relu_mask"))
         a.z_split = int(bool(it.get("z_split", False)))
+        a.residual_split = int(bool(it.get("residual_split", False)))
         a.stat_ranks = ranks
         if training and it.get("partial") is not None:
             part, nch = it["partial"]                   # partial sums left by the convolution's epilogue (phases 6)

@@ -44,7 +44,7 @@ def test_header_symbols_exported_and_prototypes_match():
         assert got == want, f"{name}: ctypes {got} != header {want}"
     for name in list(_lib.PROTOTYPES) + list(_lib.RAW_PROTOTYPES):
         assert name in decls, f"{name} bound in _lib.py but missing from hrseg.h"
-    assert _lib.abi_version() == _lib.ABI_VERSION == 14
+    assert _lib.abi_version() == _lib.ABI_VERSION == 15
     assert not any(n.startswith("hrseg_debug_") for n in decls), "experimental switches do not belong in the public header"
 
 
