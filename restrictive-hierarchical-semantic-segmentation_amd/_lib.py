@@ -306,7 +306,7 @@ class Tape:
     overlap of the eager step is kept, host callbacks (the bucketed gradient all-reduce) run where they ran, and the
     library still plans every launch itself (tile plans, scratch rings) exactly as in the eager step.
 
-    Entries: (0, cfunc, args, raw stream) | (1, waiting torch stream or None = main, signalling stream or None = main) |
+    Entries: (0, cfunc, args, raw stream) | (1, waiting torch stream or None = main, signalling stream or None = main, event) |
     (2, callable).  The main stream is whatever stream is current when replay() is called."""
 
     def __init__(self):
@@ -336,9 +336,9 @@ class Tape:
                 rc = a(*b, cur if c == rec else c)
                 if rc != 0:
                     raise RuntimeError(f"{a.__name__} failed ({rc}) in a launch-tape replay: {last_error()}")
-            elif kind == 1:
-                (a if a is not None else torch.cuda.current_stream()).wait_stream(
-                    b if b is not None else torch.cuda.current_stream())
+            elif kind == 1:         # (the entry's own event, created once: wait_stream builds and destroys one per call)
+                c.record(b if b is not None else torch.cuda.current_stream())
+                (a if a is not None else torch.cuda.current_stream()).wait_event(c)
             else:
                 a()
 
@@ -365,7 +365,7 @@ def tape_release():
 def stream_wait(waiter, signaller):
     """waiter.wait_stream(signaller) for two torch streams (None = the current stream), recorded when a tape is active"""
     if _tape is not None:
-        _tape.entries.append((1, waiter, signaller, None))
+        _tape.entries.append((1, waiter, signaller, torch.cuda.Event()))
     (waiter if waiter is not None else torch.cuda.current_stream()).wait_stream(
         signaller if signaller is not None else torch.cuda.current_stream())
 

@@ -258,7 +258,12 @@ def test_presplit_activations(name, monkeypatch):
             for a, b in zip(res[2][0][1:], res[0][0][1:]):
                 assert abs(a - b) < 1e-3 * abs(b), (res[2][0], res[0][0])
             for k, v in res[0][1].items():
-                if v.dtype.is_floating_point:
+                if not v.dtype.is_floating_point:
+                    continue
+                if "running_" in k:      # statistics of steps 2 and 3 are taken on activations of weights +-lr apart (64-pixel net:
+                    d = res[2][1][k] - v       # the lowest branch normalises over 8 samples); compared in the L2 sense
+                    assert float(d.norm()) < 1e-1 * float(v.norm()) + 1e-4, k          # (observed up to 3e-2 on a 4 x 4 fuse layer)
+                else:
                     assert float((res[2][1][k] - v).abs().max()) < 6.5e-3 + 1e-3 * float(v.abs().max()), k     # 3 steps x +-lr x 2
     finally:
         _lib.set_deterministic(False)

@@ -45,7 +45,8 @@ if what in ("tape", "both"):
             a(*b, cur if c == rec else c)
             key = a.__name__
         elif kind == 1:
-            (a if a is not None else torch.cuda.current_stream()).wait_stream(b if b is not None else torch.cuda.current_stream())
+            c.record(b if b is not None else torch.cuda.current_stream())
+            (a if a is not None else torch.cuda.current_stream()).wait_event(c)
             key = "(stream wait)"
         else:
             a()
