@@ -198,7 +198,9 @@ def probe_dominant_kernel(device, batch, size, conv_dtype="auto"):
             "executed_mfma_tflops": round(3 * ach, 1), "algorithmic_vs_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 3),
             "mfma_busy": busy, "mfma_busy_source": bsrc,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM read+write)", "traffic_source": src,
-            "avg_launch_us": round(t * 1e6, 2), "avg_launch_note": "launch = sp_weight_image_kernel + igemm_patch_ws_group_kernel",
+            "avg_launch_us": round(t * 1e6, 2),
+            "avg_launch_note": "launch = sp_weight_image_kernel + igemm_patch_ws_group_kernel (the probe's weights are scratch tensors; in the "
+                               "train step the images are persistent and the launch is the convolution kernel alone: see profiles/%s_*)" % PMC_PROFILE,
             "flop_per_launch": flops}
 
 
