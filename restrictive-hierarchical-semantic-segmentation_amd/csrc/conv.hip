@@ -900,7 +900,8 @@ static int dispatch_wgrad_group(WgradArgs* a, int n, int prec, hipStream_t st) {
 }
 
 // --------------------------------------------------------------------------- nine-tap weight gradient (workspace + ordered reduce)
-static int g_wg9_blocks = 0;           // hrseg_tune "wgrad9_blocks": target blocks per problem (0 = 256)
+static int g_wg9_blocks = 0;           // hrseg_tune "wgrad9_blocks": target blocks per problem (0 = the table below)
+static int g_wg9_blocks_n[WG9_MAXG + 1] = {0, 0, 0, 0, 0};   // hrseg_tune "wgrad9_blocks1" .. "wgrad9_blocks4": the same, per group size
 static int g_wg9 = 1;                  // hrseg_tune "wgrad9": 0 = never use the nine-tap kernel
 // tiles per side of the dW tile (3: channels multiple of 48, 4: multiple of 64), 0 = not a nine-tap case
 static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
@@ -909,16 +910,19 @@ static int wgrad9_tnk(const hrseg_conv_shape_t& s) {
   if (s.Cin % 64 == 0 && s.Cout % 64 == 0) return 4;
   return 0;
 }
-// `group_n` problems share the launch: two blocks fit a CU, so the launch's blocks should fill whole rounds of 512 --
-// 256 per problem for one, two or four problems; 160 for three (ONE round of 480 blocks, all resident at once: 104 us
-// against 119 us for two rounds of 1024 / 3 per problem, tools/wgrad9_sweep.py; four problems in one round -- 128 each --
-// measure slower than two rounds, 164 against 157 us)
+// Target blocks per problem by the number of problems sharing the launch.  Alone on the GPU the kernel likes whole rounds
+// of 512 resident blocks (256 per problem; tools/wgrad9_sweep.py), but in the train step it runs on the side stream beside
+// the data-gradient chain, and there fewer, longer blocks win: less workspace to write and reduce, and CUs left over for
+// the main stream.  Step-level sweep at the headline geometry (bench.py, 20 steps, two runs each, profiles/README.md r04):
+// 2 problems 128 (-0.2 ms against 256), 3 problems 128 (-0.65 ms against 160), 4 problems 96 (-0.5 ms against 256);
+// a single problem (UNet, HRNet stage 1) keeps 256 -- UNet loses 1.5 ms at 128.
+static const int WG9_TARGET[5] = {256, 256, 128, 128, 96};
 static void wgrad9_plan(const hrseg_conv_shape_t& s, int tnk, Wgrad9Args& a, int group_n) {
   a.B = s.B; a.H = s.Hi; a.W = s.Wi; a.Cin = s.Cin; a.Cout = s.Cout; a.ldx = s.ldx; a.lddy = s.ldy;
   a.tiles_x = ceil_div(s.Wi, 16); a.tiles_y = ceil_div(s.Hi, 4);
   a.ntiles = s.B * a.tiles_x * a.tiles_y;
   const int npairs = (s.Cout / (16 * tnk)) * (s.Cin / (16 * tnk));
-  const int target = g_wg9_blocks ? g_wg9_blocks : (group_n == 3 ? 160 : 256);
+  const int target = g_wg9_blocks_n[group_n] ? g_wg9_blocks_n[group_n] : g_wg9_blocks ? g_wg9_blocks : WG9_TARGET[group_n < 4 ? group_n : 4];
   int chunks = ceil_div(target, npairs);
   if (chunks > a.ntiles) chunks = a.ntiles;
   if (chunks < 1) chunks = 1;
@@ -1422,7 +1426,7 @@ extern "C" int hrseg_tune(const char* key, int value) {
       {"igemm_wtm", &g_tune_wtm}, {"igemm_kc", &g_tune_kc}, {"igemm_db", &g_tune_db}, {"igemm_ksplit", &g_tune_ksplit},
       {"group_wtm", &g_group_wtm}, {"wgrad_pix", &g_tune_wg_pix}, {"wgrad_db", &g_tune_wg_db},
       {"wgrad_blocks", &g_tune_wg_blocks}, {"wgrad_group_mult", &g_wg_mult}, {"wgrad_group_min", &g_wg_min},
-      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"ws_epi_early", &g_ws_epi_early}, {"exp_nosplit_x", &g_exp_nosplit}, {"x_split", &g_x_split}, {"ws_epi_cost", &g_ws_epi_cost}, {"ws_epi_acc_cost", &g_ws_epi_acc_cost}, {"wgrad9_blocks", &g_wg9_blocks}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
+      {"wgrad_group_max", &g_wg_max}, {"sp_wtm", &g_sp_wtm}, {"sp_wtn", &g_sp_wtn}, {"sp_ksplit", &g_sp_ksplit}, {"sp_patch", &g_sp_patch}, {"sp_persist", &g_sp_persist}, {"sp_ws", &g_sp_ws}, {"sp_ws_waste", &g_ws_waste}, {"small_cin3", &g_small_cin3}, {"sp_ws_bf16", &g_ws_bf16}, {"sp_ws_n48", &g_ws_n48}, {"sp_img", &g_sp_img}, {"wgrad9", &g_wg9}, {"ws_epi_early", &g_ws_epi_early}, {"exp_nosplit_x", &g_exp_nosplit}, {"x_split", &g_x_split}, {"ws_epi_cost", &g_ws_epi_cost}, {"ws_epi_acc_cost", &g_ws_epi_acc_cost}, {"wgrad9_blocks", &g_wg9_blocks}, {"wgrad9_blocks1", &g_wg9_blocks_n[1]}, {"wgrad9_blocks2", &g_wg9_blocks_n[2]}, {"wgrad9_blocks3", &g_wg9_blocks_n[3]}, {"wgrad9_blocks4", &g_wg9_blocks_n[4]}, {"sp_wide", &g_sp_wide}, {"sp_ws_canvas", &g_ws_canvas}, {"wgrad_group_sp", &g_wg_group_sp}, {"wgrad_sp_t5", &g_wg_t5}, {"wgrad_sp_wide", &g_wg_wide}, {"sp_wide_min_blocks", &g_spw_min_blocks},
       {"sp_patch_min_tiles", &g_patch_min_tiles}, {"auto_min_pixels", &g_auto_min_pix}, {"sp_ws_min_tiles", &g_ws_min_tiles},
       {"deterministic", &hrseg_g_deterministic}};
   HRSEG_CHECK_ARG(key != nullptr, "hrseg_tune: null key");

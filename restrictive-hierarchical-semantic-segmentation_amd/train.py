@@ -391,6 +391,7 @@ class TapedTrainStep:
         optimizer._sync_hyper(dev)
         _lib.ensure_scratch(dev)
         _lib.ensure_image_arena(m._flat)
+        self._flat = m._flat                    # the tape holds raw pointers into these buffers
         self.pool = torch.cuda.MemPool()
         self.tape = _lib.Tape()
         self.replays = 0
@@ -467,6 +468,10 @@ class TapedTrainStep:
 
     def __call__(self, data, target):
         """-> (packed scalars of the step [device], per-level confusion matrices): `unpack` reads them on the host"""
+        m = _unwrap(self.model)
+        if m._flat is not self._flat or not self._flat.valid(self.x.device):
+            raise RuntimeError("TapedTrainStep: the model's parameters were moved (.to() / .cuda() / re-flattened) after the step "
+                               "was recorded; record a new one")
         self._load(data, target)
         self.optimizer._sync_hyper(self.x.device)
         self.optimizer._step += 1
@@ -537,7 +542,7 @@ def taped_step_for(model, optimizer, lossFuncts, args, class_tree, data, target,
     if getattr(args, "level0_pretrain_epochs", None) is not None:
         cap = int(epoch_num // args.level0_pretrain_epochs)
     import torch.distributed as dist
-    key = (tuple(data.shape), tuple(target.shape), id(optimizer), cap, getattr(m, "conv_dtype", None),
+    key = (tuple(data.shape), tuple(target.shape), id(optimizer), id(m.flatten_parameters(data.device)), cap, getattr(m, "conv_dtype", None),
            bool(getattr(m, "dedup_passes", False)), bool(getattr(m, "sequential_passes", False)),
            bool(getattr(m, "sync_bn", False)), _lib.deterministic(), _lib.tune_generation(), id(m._grad_hook),
            dist.is_available() and dist.is_initialized() and dist.get_world_size(), m.training,
