@@ -1504,6 +1504,20 @@ __device__ __forceinline__ float sp_row16_sum(float v) {
   return v;
 }
 
+// s_waitcnt vmcnt(n) tied to the register a load fills (n: a constant once the slab loop is unrolled)
+__device__ __forceinline__ void sp_wait_vm(f32x4& r, int n) {
+  switch (n) {
+#define HRSEG_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r)); break;
+    HRSEG_VM(0) HRSEG_VM(1) HRSEG_VM(2) HRSEG_VM(3) HRSEG_VM(4) HRSEG_VM(5) HRSEG_VM(6) HRSEG_VM(7) HRSEG_VM(8) HRSEG_VM(9)
+    HRSEG_VM(10) HRSEG_VM(11) HRSEG_VM(12) HRSEG_VM(13) HRSEG_VM(14) HRSEG_VM(15) HRSEG_VM(16) HRSEG_VM(17) HRSEG_VM(18) HRSEG_VM(19)
+    HRSEG_VM(20) HRSEG_VM(21) HRSEG_VM(22) HRSEG_VM(23) HRSEG_VM(24) HRSEG_VM(25) HRSEG_VM(26) HRSEG_VM(27) HRSEG_VM(28) HRSEG_VM(29)
+    HRSEG_VM(30) HRSEG_VM(31) HRSEG_VM(32) HRSEG_VM(33) HRSEG_VM(34) HRSEG_VM(35) HRSEG_VM(36) HRSEG_VM(37) HRSEG_VM(38) HRSEG_VM(39)
+    HRSEG_VM(40) HRSEG_VM(41) HRSEG_VM(42) HRSEG_VM(43) HRSEG_VM(44) HRSEG_VM(45) HRSEG_VM(46) HRSEG_VM(47) HRSEG_VM(48)
+#undef HRSEG_VM
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)); break;
+  }
+}
+
 template <int NS, int TH, int WTN, int CS, int FLIP>
 __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned char* lds, const int first, const int end,
                                                     const int block_row = 0) {
@@ -1517,7 +1531,16 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   constexpr int P_LOADS = (PP + PR - 1) / PR;              // rounds per K stage
   constexpr int W16 = L::WSTAGE / 16, W_LOADS = (W16 + 255) / 256;     // 16-byte granules of a pre-split weight slab
   constexpr int NU = 9 * CS, NSLAB = (NU + 1) / 2;
-  constexpr int D = 4;                                     // producer look-ahead, slabs
+#ifndef HRSEG_WS_PRODUCER
+#define HRSEG_WS_PRODUCER 1  // 0: the round-3 producer (one flat loop over slabs), kept for A/B builds
+#endif
+#ifndef HRSEG_WS_EXP
+#define HRSEG_WS_EXP 0       // MEASUREMENT ONLY (wrong results): 1 no MFMAs, 2 no weight loads, 4 no patch loads, 8 no weight stores, 16 no epilogue, 32 epilogue stores out of range
+#endif
+#ifndef HRSEG_WS_LOOKAHEAD
+#define HRSEG_WS_LOOKAHEAD 4
+#endif
+  constexpr int D = HRSEG_WS_LOOKAHEAD;                    // producer look-ahead, slabs (a power of two)
   static_assert(NSLAB % 2 == 0, "register-set parity must restart with every K stage");
   constexpr int GPS = (P_LOADS + NSLAB - 2 - D) / (NSLAB - 1 - D);     // patch granules per thread and slab
   constexpr int P_SLABS = (P_LOADS + GPS - 1) / GPS;                   // slabs of a stage that stage patch granules
@@ -1588,8 +1611,24 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     constexpr int NP = sp_np(NS);
     constexpr int UNITS = RPW * NP + WTN * NP;             // fragment registers (8 halfs each) of a slab
     constexpr int MM = WTN * RPW * sp_nprod(NS);           // MFMAs of a slab
+#ifndef HRSEG_WS_READ_LAG
+#define HRSEG_WS_READ_LAG 0
+#endif
+    constexpr int MR = MM > 2 * HRSEG_WS_READ_LAG ? MM - HRSEG_WS_READ_LAG : MM;     // MFMAs that carry the next slab's reads
     // fragment r of slab `slab` (compile-time) -> register set
-    auto read_unit = [&](int slab, int wboff, int pbuf, int r, bf16x8 (&xf)[RPW][NP], bf16x8 (&wf)[WTN][NP]) {
+    // A pixel fragment's LDS address is (patch pixel prow0 + c) * 32 + the 8-byte slot g, swizzled by bit 3 of the pixel index,
+    // c = m * PW + tap offset a compile-time constant.  The swizzle depends on c only through c mod 16, so SIXTEEN per-lane base
+    // registers (xbase[j]: the lane's pixel prow0, slot swizzled for c = j mod 16, the patch buffer the reads currently target)
+    // serve every fragment read with an immediate offset -- left to itself the compiler keeps one address register per
+    // (row, tap) pair, ~40-57 loop-invariant registers on the 16-row tiling, which is what made these kernels spill.
+    int xbase[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xbase[j] = pbase + ((g ^ (2 * (((prow0 + j) >> 3) & 1))) << 3);
+    auto xbase_flip = [&](int to_buf) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xbase[j] += to_buf ? L::PATCH : -L::PATCH;
+    };
+    auto read_unit = [&](int slab, int wboff, int r, bf16x8 (&xf)[RPW][NP], bf16x8 (&wf)[WTN][NP]) {
       if (r < RPW * NP) {
         const int m = r / NP, q = r % NP;
         const int uA = 2 * slab, uB = 2 * slab + 1;
@@ -1597,13 +1636,11 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
         const int tB = (uB < NU) ? uB / CS : 0, cB = (uB < NU) ? uB - tB * CS : 0;
         const int dA = (FLIP ? 2 - tA / 3 : tA / 3) * PW + (FLIP ? 2 - tA % 3 : tA % 3);
         const int dB = (FLIP ? 2 - tB / 3 : tB / 3) * PW + (FLIP ? 2 - tB % 3 : tB % 3);
-        const unsigned char* pb = lpatch + pbuf * L::PATCH + q * L::PPIECE;
-        const int pa = prow0 + m * PW + dA, pbx = prow0 + m * PW + dB;
-        const int oa = cA * L::CHUNK + pbase + (m * PW + dA) * 32 + ((g ^ (2 * ((pa >> 3) & 1))) << 3);
-        const int ob = cB * L::CHUNK + pbase + (m * PW + dB) * 32 + ((g ^ (2 * ((pbx >> 3) & 1))) << 3);
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(pb + oa);
+        const unsigned char* pb = lpatch + q * L::PPIECE;
+        const int ca = m * PW + dA, cb = m * PW + dB;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(pb + xbase[ca & 15] + (cA * L::CHUNK + ca * 32));
         u32x2 hi = u32x2{0u, 0u};
-        if (uB < NU) hi = *reinterpret_cast<const u32x2*>(pb + ob);
+        if (uB < NU) hi = *reinterpret_cast<const u32x2*>(pb + xbase[cb & 15] + (cB * L::CHUNK + cb * 32));
         xf[m][q] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
       } else {
         const int i = r - RPW * NP, n = i / NP, q = i % NP;
@@ -1664,7 +1701,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
       for (int m = 0; m < RPW; ++m) {
         const int oy = q.y0 + wave * RPW + m;
-        off[m] = (ook & (oy < H)) ? (unsigned)((obc * H + oy) * W + ox) * ld4 + (unsigned)(q.nt * BN + 4 * g) * 4u : HRSEG_BUF_OOB;
+        off[m] = (!(HRSEG_WS_EXP & 32) & ook & (oy < H)) ? (unsigned)((obc * H + oy) * W + ox) * ld4 + (unsigned)(q.nt * BN + 4 * g) * 4u : HRSEG_BUF_OOB;
       }
     };
     auto fetch_add = [&](const Geom& q) {
@@ -1756,7 +1793,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     Geom cur = tile_geom(first);
     __syncthreads();                       // the producers' prologue: first patch, weight slabs 0 and 1
 #pragma unroll
-    for (int r = 0; r < UNITS; ++r) read_unit(0, 0, 0, r, xfr[0], wfr[0]);
+    for (int r = 0; r < UNITS; ++r) read_unit(0, 0, r, xfr[0], wfr[0]);
     zero_acc();
     int wb = 0, pb = 0;                    // weight buffer offset of the CURRENT slab, patch buffer of the CURRENT stage
     for (int t = first;; ++t) {
@@ -1770,7 +1807,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           // the next slab's fragments: slab s+1 of this patch, or slab 0 of the next stage's patch (complete since
           // the barrier before this slab; past the block's last stage the reads fetch stale data nobody uses)
           const int nslab = (s + 1 < NSLAB) ? s + 1 : 0;
-          const int npb = (s + 1 < NSLAB) ? pb : pb ^ 1;
+          if (s + 1 == NSLAB) xbase_flip(pb ^ 1);          // (every read of a stage's last slab targets the next stage's patch)
           int k = 0;
 #pragma unroll
           for (int pr = 0; pr < sp_nprod(NS); ++pr) {
@@ -1782,24 +1819,37 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
                 if (NS == 4) {
                   const f16x8 wv = __builtin_bit_cast(f16x8, wfr[s & 1][n][pr == 0 ? NP - 1 : 0]);
                   const f16x8 xv = __builtin_bit_cast(f16x8, xfr[s & 1][m][pr == 1 ? NP - 1 : 0]);
+#if HRSEG_WS_EXP & 1
+                  asm volatile("" :: "v"(wv), "v"(xv));
+#else
                   acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[n][m], 0, 0, 0);
+#endif
                 } else {
                   acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s & 1][n][0], xfr[s & 1][m][0], acc[n][m], 0, 0, 0);
                 }
+                // the next slab's reads go out behind the slab's first MR MFMAs: the last HRSEG_WS_READ_LAG MFMAs cover their
+                // latency, so that the wait before the slab barrier finds them complete
 #pragma unroll
-                for (int r = k * UNITS / MM; r < (k + 1) * UNITS / MM; ++r)
-                  read_unit(nslab, wb1, npb, r, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
+                for (int r = (k < MR ? k : MR) * UNITS / MR; r < (k + 1 < MR ? k + 1 : MR) * UNITS / MR; ++r)
+                  read_unit(nslab, wb1, r, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 ++k;
               }
             }
           }
+#if HRSEG_WS_EXP & 16
+          if (s == NSLAB - 1 && last_ks) {
+            if (acc[0][0][0] == 1.2345f) store_acc(cur);
+            zero_acc();
+          }
+#else
           if (PF && s == S_PF && last_ks && e_early) fetch_add(cur);
           if (s == NSLAB - 1 && last_ks) {
             if (!(PF && e_early)) fetch_add(cur);
             store_acc(cur);
             zero_acc();
           }
+#endif
           // The slab barrier orders LDS traffic only (the producers' ds_writes against these reads).  __syncthreads() would
           // also wait for every outstanding vector-memory operation of this wave (its workgroup-scope fence emits vmcnt(0)):
           // the tile's stores after store_acc -- a memory round trip per tile before the next tile's first slab -- and the
@@ -1814,7 +1864,9 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
       if (!have_next) break;
     }
+#if !HRSEG_WS_PRODUCER
     for (int k = total; k & (D - 1); ++k) __builtin_amdgcn_s_barrier();      // the producers' loop is unrolled by D slabs
+#endif
     if (SREG && e_sreg) {          // the register sums of this wave: row reduction, then one fp64 LDS atomic per channel and sum
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
@@ -1829,6 +1881,249 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
     }
   } else {
+#if HRSEG_WS_PRODUCER
+    // PRODUCERS.  A wave issues an instruction every four or five cycles at best and the block meets at ONE barrier per slab, so a
+    // slab lasts as long as its slowest wave's instruction stream: a 36-MFMA slab is 576 cycles of the matrix pipe, i.e. ~120
+    // producer instructions.  (Round 4 measured the previous flat-loop producer -- ~230 instructions per slab on the 16-row
+    // tiling, a third of them per-granule address arithmetic with quarter-rate 32-bit multiplies -- as what set the slab time:
+    // 2,240 / 1,340-1,710 cycles per slab on 16-row / 96-channel tiles, 1,450 / 990-1,140 with the loads and their address
+    // arithmetic compiled out, tools/ws_bound.py.)  This producer runs K stage by K stage with the slab loop of a stage unrolled
+    // (every condition on the slab index folds away), and everything about a patch granule that does not depend on the tile --
+    // its pixel of the patch, its offset from the patch origin, its LDS address -- is computed ONCE per block:
+    //   * weights: slab j+2 goes from the register ring (loaded D slabs earlier) to LDS, slab j+2+D is loaded into the same
+    //     registers: one address add per load / store group, the image offset of the stage is a scalar;
+    //   * patch of the NEXT stage, granule by granule (loaded at slab s, split and stored at slab s+D): an interior tile's
+    //     granule loads with its precomputed offset as the vector offset and the tile origin as the scalar offset -- no
+    //     vector instruction at all; a border or canvas tile pays eight (row / column range tests against per-stage scalars);
+    //   * waits are counted: the number of loads younger than the one a store needs is a compile-time function of the slab.
+    float xscale, xinv;
+    sp_pow2_scale(p.xmax, xscale, xinv);
+    const int per_tile = nks * NSLAB;                      // slabs (= weight image entries) per tile
+    auto rsrc_words = [](const void* base, size_t bytes) {
+      const unsigned long long a = (unsigned long long)base;
+      i32x4_t r;
+      r[0] = (int)(unsigned)(a & 0xffffffffull);
+      r[1] = (int)(unsigned)((a >> 32) & 0xffffull);
+      r[2] = (int)(unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes);
+      r[3] = HRSEG_BUF_FLAGS;
+      return r;
+    };
+    auto ld16 = [](f32x4& dst, const i32x4_t& rs, unsigned voff, unsigned soff) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    const i32x4_t rw = rsrc_words(p.wimg, (size_t)ntn * per_tile * L::WSTAGE);
+    // ---- what a thread's patch granules are, once per block
+    const int pix0 = ptid / GPP, prem = ptid - pix0 * GPP;
+    const bool pwork = pix0 < PR;                          // (CS = 3: the last four threads stage no patch granule)
+    const int pst0 = (prem >> 2) * L::CHUNK, pq = prem & 3;
+    const unsigned ldx4 = (unsigned)p.ldx * 4u;
+    unsigned rel[P_LOADS];          // byte offset of the granule from the patch origin (row y0-1, column x0-1) of a plain image
+    int lst[P_LOADS];               // its LDS byte offset inside a patch buffer (piece 0)
+    int gpy[P_LOADS], gpx[P_LOADS]; // its patch row and column (row: a value no image reaches for a granule that does not exist)
+#pragma unroll
+    for (int i = 0; i < P_LOADS; ++i) {
+      const int pix = pix0 + PR * i;
+      const int py = (pix * 3641) >> 16, px = pix - py * PW;           // pix / 18 for pix < 2^12
+      const bool ex = pwork & (pix < PP);
+      rel[i] = ex ? (unsigned)(py * W + px) * ldx4 + (unsigned)prem * 16u : HRSEG_BUF_OOB;
+      // a granule that does not exist stores zeros into the padding behind chunk 0's pixels (CHUNK is PP * 32 + 192 bytes)
+      lst[i] = ex ? pst0 + pix * 32 + ((pq ^ (2 * ((pix >> 3) & 1))) << 3) : PP * 32 + (lane & 15) * 8;
+      gpy[i] = ex ? py : 0x40000000;
+      gpx[i] = px;
+    }
+    static_assert(L::CHUNK - PP * 32 >= 128 + 8, "the padding of a chunk image takes the stores of granules that do not exist");
+    // weights: 16-byte granule f = ptid + 256 i of a slab
+    unsigned wv[W_LOADS];
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) wv[i] = (ptid + 256 * i < W16) ? (unsigned)(ptid + 256 * i) * 16u : 0x80000000u;
+    const bool wlast = __builtin_amdgcn_readfirstlane((int)((wave - 4) * 64 + 256 * (W_LOADS - 1) < W16)) != 0;   // wave-uniform
+    const int wl0 = (int)(lw - lds) + ptid * 16;
+    const int exp_nosplit = p.exp_nosplit | p.x_presplit;        // x stored pre-split: copy, do not split (see hrseg.h x_split)
+    // ---- per-stage scalars of the stage whose patch is being staged
+    struct Stage { unsigned tb, tb0, delta; int y0m1, x0m1, xlo, xspan, xb; bool fast, second; };
+    const unsigned hw = (unsigned)(H * W);
+    auto stage_scalars = [&](const Geom& q) {
+      Stage z;
+      const int x0m1 = q.x0 - 1;
+      z.y0m1 = q.y0 - 1;
+      z.x0m1 = x0m1;
+      z.xlo = x0m1 < 0 ? 1 : 0;
+      if (cv_w1 > 0) {
+        const int bc0 = x0m1 < 0 ? 0 : (int)__umulhi((unsigned)x0m1, cv_magic);
+        z.xb = (bc0 + 1) * cv_w1 - x0m1;
+        z.second = bc0 + 1 < cv_nb;
+        z.tb0 = ((unsigned)((bc0 * H + z.y0m1) * W + x0m1 - bc0 * cv_w1)) * ldx4;
+        z.delta = (hw - (unsigned)cv_w1) * ldx4;
+        z.fast = false;
+        if (bc0 >= cv_nb) z.xb = z.xlo + 1;               // (a tile column past the last image: nothing valid)
+      } else {
+        z.xb = W - x0m1 + 1;
+        z.second = false;
+        z.tb0 = (unsigned)(z.y0m1 * W + x0m1) * ldx4;
+        z.delta = 0u;
+        z.fast = (q.y0 >= 1) & (q.y0 + TH + 1 <= H) & (q.x0 >= 1) & (q.x0 + 17 <= W);
+      }
+      z.xspan = z.xb - 1 - z.xlo;
+      z.tb = z.tb0;
+      return z;
+    };
+    const bool cv_narrow = cv_w1 > 0 && cv_w1 < 18;       // an 18-column patch may span three images: exact per-granule arithmetic
+    auto patch_voff = [&](const Stage& z, int i) -> unsigned {          // border / canvas tile: the granule's offset or OOB
+      if (cv_narrow) {
+        const int iy = gpy[i] + z.y0m1, cx = gpx[i] + z.x0m1;
+        const int bc = (int)__umulhi((unsigned)cx, cv_magic);
+        const int ix = cx - bc * cv_w1;
+        const bool ok = ((unsigned)iy < (unsigned)H) & (cx >= 0) & (ix < W) & (bc < cv_nb);
+        return ok ? (unsigned)((bc * H + iy) * W + ix) * ldx4 + (unsigned)prem * 16u : HRSEG_BUF_OOB;
+      }
+      const bool oky = (unsigned)(gpy[i] + z.y0m1) < (unsigned)H;
+      const bool ok1 = (unsigned)(gpx[i] - z.xlo) < (unsigned)z.xspan;
+      const bool ok2 = z.second & (gpx[i] >= z.xb);
+      const unsigned off = rel[i] + z.tb0 + (ok2 ? z.delta : 0u);
+      return (oky & (ok1 | ok2)) ? off : HRSEG_BUF_OOB;
+    };
+    auto patch_store1 = [&](const f32x4& v, int i, int pboff) {
+      u32x2 pc[sp_np(NS)];
+      if (exp_nosplit) {
+        const u32x4 raw = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int s = 0; s < sp_np(NS); ++s) pc[s] = u32x2{raw[(2 * s) & 3], raw[(2 * s + 1) & 3]};
+      } else {
+        sp_split4<NS>(v, pc, xscale);
+      }
+      const int o = pboff + lst[i];
+#pragma unroll
+      for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
+    };
+    auto image_rsrc = [&](int b) { return rsrc_words(p.x + (size_t)b * H * W * p.ldx, (size_t)cv_nb * H * W * p.ldx * 4); };
+    // image offset of the weight slabs of stage (channel tile nt, K stage ks)
+    auto stage_woff = [&](int nt, int ks) { return (unsigned)((nt * nks + ks) * NSLAB) * (unsigned)L::WSTAGE; };
+    // Registers in flight.  Weights: a ring of DW = 2 slab sets -- a stage has an even number of slabs, so every stage starts at
+    // ring position 0 and the loop's back edge maps each register to itself.  (The loads are inline assembly the compiler knows
+    // nothing about: a ring whose phase alternates between stages needs two code instances and a join between them, and at
+    // that join the compiler MOVED ring registers whose loads were still in flight -- measured, wrong results.)  Patch: one
+    // register set per granule of the stage, loaded GPL per slab from slab 0 and stored DP slabs later -- nothing of it is in
+    // flight across a stage boundary.
+    constexpr int DW = 2;
+    constexpr int GPL = (P_LOADS + NSLAB - 6) / (NSLAB - 5);           // granules loaded per slab so that DP >= 4
+    constexpr int DP = NSLAB - 1 - (P_LOADS + GPL - 1) / GPL;          // the last granule is stored at slab NSLAB - 2
+    static_assert(DP >= 4 && (P_LOADS + GPL - 1) / GPL <= NSLAB - DW, "patch schedule");
+    f32x4 rw4[DW][W_LOADS], pg[P_LOADS];
+    Geom cur = tile_geom(first);
+    // ---- prologue: the first patch and weight slabs 0, 1 into LDS, slabs 2 .. D+1 in flight
+    unsigned woff_cur = stage_woff(cur.nt, 0);             // weight image offset of the CURRENT stage's slab 0
+    {
+      f32x4 v[P_LOADS];
+      const i32x4_t rx0 = image_rsrc(cur.b);
+      const Stage z0 = stage_scalars(cur);
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) ld16(v[i], rx0, patch_voff(z0, i), 0u);
+      f32x4 w01[2][W_LOADS];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) ld16(w01[d][i], rw, wv[i] + woff_cur + (unsigned)(d * L::WSTAGE), 0u);
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]));
+#pragma unroll
+      for (int i = 0; i < P_LOADS; ++i) patch_store1(v[i], i, 0);
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w01[0][i]), "+v"(w01[1][i]));
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i)
+          if (i + 1 < W_LOADS || wlast) *reinterpret_cast<f32x4*>(lds + wl0 + d * L::WSTAGE + i * 4096) = w01[d][i];
+    }
+    // the stage after the current one (its patch is staged during the current stage; its weights follow the current stage's)
+    int n_t = first, n_ks = 0;
+    Geom nxt = cur;
+    i32x4_t rxn = image_rsrc(cur.b);
+    bool have_next = false;
+    unsigned woff_nxt = 0u;
+    auto advance = [&]() {                  // nxt := the stage after nxt
+      if (++n_ks == nks) {
+        n_ks = 0;
+        ++n_t;
+        const int b = nxt.b;
+        tile_next(nxt);
+        if (nxt.b != b) rxn = image_rsrc(nxt.b);
+      }
+      have_next = n_t < end;
+      woff_nxt = stage_woff(nxt.nt, n_ks);
+    };
+    advance();
+    // slab k (0 <= k < 2 NSLAB, counted from the current stage's slab 0) -> its byte offset in the weight image
+    auto slab_woff = [&](int k) { return k < NSLAB ? woff_cur + (unsigned)(k * L::WSTAGE) : woff_nxt + (unsigned)((k - NSLAB) * L::WSTAGE); };
+    static_assert(2 + 2 * DW <= NSLAB, "weight look-ahead stays within the next stage");
+#pragma unroll
+    for (int d = 0; d < DW; ++d)
+#pragma unroll
+      for (int i = 0; i < W_LOADS; ++i) ld16(rw4[(d + 2) % DW][i], rw, wv[i] + slab_woff(d + 2), 0u);
+    __syncthreads();
+    int wb2 = 2 * L::WSTAGE;               // LDS weight buffer of slab j+2
+    int pboff = 0;                         // patch buffer of the current stage (byte offset)
+    // loads of slab s, in issue order: W_LOADS weight loads, then nl(s) patch loads (granules s GPL .. of the next stage's patch)
+    auto nl = [](int s) { s = ((s % NSLAB) + NSLAB) % NSLAB; const int r = P_LOADS - s * GPL; return r < 0 ? 0 : (r > GPL ? GPL : r); };
+    const int nstages = (end - first) * nks;
+    int q = 0;
+    do {                                    // one K stage per iteration (at least one: first < end)
+      const Stage z = stage_scalars(nxt);
+      const i32x4_t rx = have_next ? rxn : rsrc_words(p.x, 0);       // (no next stage: a descriptor of size 0, every load out of range)
+      const unsigned soff = z.tb + (unsigned)(n_ks * CS * 64);
+      const unsigned ksoff = (unsigned)(n_ks * CS * 64);
+#pragma unroll
+      for (int s = 0; s < NSLAB; ++s) {
+        // ---- weights: slab s+2 -> LDS, slab s+2+DW -> registers
+        {
+          int yw = nl(s - DW);
+#pragma unroll
+          for (int k = s - DW + 1; k < s; ++k) yw += W_LOADS + nl(k);
+          f32x4 (&wset)[W_LOADS] = rw4[s % DW];
+#pragma unroll
+          for (int i = 0; i < W_LOADS; ++i) sp_wait_vm(wset[i], yw);
+          const int a = wl0 + wb2;
+#pragma unroll
+          for (int i = 0; i < W_LOADS; ++i)
+            if (!(HRSEG_WS_EXP & 8) && (i + 1 < W_LOADS || wlast)) *reinterpret_cast<f32x4*>(lds + a + i * 4096) = wset[i];
+          const unsigned wo = slab_woff(s + 2 + DW);
+#pragma unroll
+          for (int i = 0; i < W_LOADS; ++i) ld16(wset[i], rw, (HRSEG_WS_EXP & 2) ? HRSEG_BUF_OOB : wv[i] + wo, 0u);
+        }
+        // ---- patch of the next stage: the granules loaded at slab s-DP are stored, nl(s) granules are loaded
+        if (s >= DP && nl(s - DP) > 0) {
+          int yp = W_LOADS;
+#pragma unroll
+          for (int k = s - DP + 1; k < s; ++k) yp += W_LOADS + nl(k);
+#pragma unroll
+          for (int e = 0; e < GPL; ++e)
+            if (e < nl(s - DP)) sp_wait_vm(pg[(s - DP) * GPL + e], yp + nl(s - DP) - 1 - e);
+          if (have_next) {
+#pragma unroll
+            for (int e = 0; e < GPL; ++e)
+              if (e < nl(s - DP)) patch_store1(pg[(s - DP) * GPL + e], (s - DP) * GPL + e, L::PATCH - pboff);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < GPL; ++e) {
+          if (e < nl(s)) {
+            const int i = s * GPL + e;
+            if (HRSEG_WS_EXP & 4) ld16(pg[i], rx, HRSEG_BUF_OOB, 0u);
+            else if (z.fast) ld16(pg[i], rx, rel[i], soff);
+            else ld16(pg[i], rx, patch_voff(z, i), ksoff);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the LDS stores; the loads in flight stay in flight)
+        __builtin_amdgcn_s_barrier();
+        wb2 = (wb2 == 2 * L::WSTAGE) ? 0 : wb2 + L::WSTAGE;
+      }
+      pboff = L::PATCH - pboff;
+      woff_cur = woff_nxt;
+      advance();
+    } while (++q < nstages);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead loads of slabs past the block's last
+#else
+
     // Producers run a flat loop over the block's slabs (j = 0 .. total-1, indices runtime and wave-uniform): at slab j
     // they store weight slab j+2 (loaded four slabs earlier into register set (j+2)%4) and issue the loads of slab
     // j+6 into the same set; the next K stage's patch goes granule by granule, loaded at in-stage slab s and stored
@@ -1870,7 +2165,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       const int iy = q.y0 - 1 + py, cx = q.x0 - 1 + px;
       const int bc = (int)__umulhi((unsigned)cx, cv_magic);             // image on the canvas (0 in plain mode)
       const int ix = cx - bc * cv_w1;
-      const bool ok = valid & pwork & (pix < PP) & ((unsigned)iy < (unsigned)H) & (cx >= 0) & (ix < W) & (bc < cv_nb);
+      const bool ok = !(HRSEG_WS_EXP & 4) & valid & pwork & (pix < PP) & ((unsigned)iy < (unsigned)H) & (cx >= 0) & (ix < W) & (bc < cv_nb);
       const unsigned off = ok ? (unsigned)((bc * H + iy) * W + ix) * ldx4 + prem16 : HRSEG_BUF_OOB;
       ld16(dst, rx, off, ks * CS * 64);
     };
@@ -1899,7 +2194,11 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
       for (int i = 0; i < W_LOADS; ++i) {
         const int f = ptid + 256 * i;
+#if HRSEG_WS_EXP & 2
+        ld16(set[i], rw, HRSEG_BUF_OOB, 0);
+#else
         ld16(set[i], rw, (f < W16 && l_t < end) ? l_off + (unsigned)f * 16u : HRSEG_BUF_OOB, 0);
+#endif
       }
       l_off += L::WSTAGE;
       if (++l_j == per_tile) {
@@ -1965,7 +2264,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
         f32x4 (&wset)[W_LOADS] = rw4[(u + 2) % D];
 #pragma unroll
         for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wset[i]) : "n"(WAIT_W));
-        if (j + u + 2 < total) w_put(wb2, wset);
+        if (!(HRSEG_WS_EXP & 8) && j + u + 2 < total) w_put(wb2, wset);
         w_issue(wset);
         // rpg[(u+2)%D] holds the granules loaded four slabs ago (the prologue's dummies shift the ring by two)
         f32x4 (&pset)[GPS] = rpg[(u + 2) % D];
@@ -1987,6 +2286,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummies before the wave ends
+#endif
   }
   if (stat) {
     // every consumer has added its last tile (LDS atomics complete before the barrier); the block's sums go out as row
