@@ -1571,7 +1571,30 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   const int nks = p.K / (16 * CS);
   if (first >= end) return;
   const int total = (end - first) * nks * NSLAB;           // slabs of this block
+#ifndef HRSEG_WS_STAMP
+#define HRSEG_WS_STAMP 0     // MEASUREMENT ONLY: block 0's waves 0 (consumer) and 4 (producer) write the time they ARRIVE at every slab barrier
+#endif                       // and the time they LEAVE it into p.stat_partial ([role][slab][2] 64-bit counters; no statistics then)
+#if HRSEG_WS_STAMP
+  const bool stat = false;
+  unsigned long long* const stamp_out = reinterpret_cast<unsigned long long*>(p.stat_partial);
+  const bool stamping = stamp_out != nullptr && block_row == 0 && (wave == 0 || wave == 4);
+  int stamp_j = 0;
+  auto stamped_barrier = [&]() {
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0" : "=s"(t0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+    if (stamping && stamp_j < 1024 && lane == 0) {
+      unsigned long long* o = stamp_out + ((wave >> 2) * 1024 + stamp_j) * 2;
+      o[0] = t0;
+      o[1] = t1;
+    }
+    ++stamp_j;
+  };
+#else
   const bool stat = p.stat_partial != nullptr;
+  auto stamped_barrier = [&]() { __builtin_amdgcn_s_barrier(); };
+#endif
   if (stat)
     for (int i = tid; i < 2 * p.N; i += 512) lstat[i] = 0.0;            // (ordered before the first epilogue by the prologue barrier)
 
@@ -1856,7 +1879,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           // loads of fetch_add issued S_PF slabs early.  Nothing another wave of the block reads depends on them, so the
           // consumers wait for their LDS operations and meet the barrier directly.
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
+          stamped_barrier();
           wb = wb1;
         }
         pb ^= 1;
@@ -2114,7 +2137,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the LDS stores; the loads in flight stay in flight)
-        __builtin_amdgcn_s_barrier();
+        stamped_barrier();
         wb2 = (wb2 == 2 * L::WSTAGE) ? 0 : wb2 + L::WSTAGE;
       }
       pboff = L::PATCH - pboff;

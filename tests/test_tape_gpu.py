@@ -103,7 +103,9 @@ def test_tape_replay_tracks_the_eager_step_in_the_default_mode():
         res[mode] = losses
     noise = max(abs(a - b) for a, b in zip(res["eager"], res["eager2"]))
     for a, b in zip(res["eager"], res["tape"]):
-        assert abs(a - b) <= max(5e-4 * abs(a), 4 * noise), (res, noise)
+        # (the 64-pixel case is chaotic from the second step on: two eager runs differ by up to ~1e-3 of the loss, and their
+        # difference in one sample of three steps can come out several times smaller than that)
+        assert abs(a - b) <= max(1e-3 * abs(a), 4 * noise), (res, noise)
 
 
 def test_recorded_body_launches_no_aten_kernel():

@@ -455,3 +455,33 @@ def test_bf16_group_launch_on_the_wave_specialised_body():
     assert _lib.launch_count("ws_group") == 1
     for i in range(4):
         assert _rel(dxs[i], ops.conv_dgrad(dys[i], wts[i], xs[i].shape, 3, 1, prec=0)) < BF16_TOL
+
+
+@pytest.mark.gpu
+def test_ws_results_do_not_depend_on_timing():
+    """The producer waves' loads are inline assembly with counted waits the compiler knows nothing about (a register copied or
+    reused while its load is in flight shows up as run-to-run differences, not as a wrong constant): every case 25 times, each
+    result bit-identical to the first.  (tools/ws_stress.py is the long form.)"""
+    from hrseg_amd import _lib, ops
+    pr = _lib.CONV_PRECISION["auto"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dev = torch.device("cuda:0")
+    for cin, cout, H, W, B in [(48, 48, 155, 155, 8), (144, 96, 78, 61, 5), (192, 192, 39, 39, 8), (64, 64, 155, 155, 4), (96, 48, 37, 45, 13)]:
+        x = torch.randn(B, H, W, cin, device=dev, generator=g)
+        w = torch.randn(cout, 9, cin, device=dev, generator=g) * 0.05
+        wt = ops.weight_transpose(w, cout, 9, cin)
+        dy = torch.randn(B, H, W, cout, device=dev, generator=g) * 1e-3
+        gm = dy.abs().max().reshape(1).repeat(64)
+        y0 = ops.conv_fwd(x, w, None, 3, 1, prec=pr).clone()
+        d0 = ops.conv_dgrad(dy, wt, x.shape, 3, 1, prec=pr, gmax=gm).clone()
+        assert torch.isfinite(y0).all() and torch.isfinite(d0).all()
+        for _ in range(25):
+            assert torch.equal(ops.conv_fwd(x, w, None, 3, 1, prec=pr), y0), (cin, cout, H, W, B)
+            assert torch.equal(ops.conv_dgrad(dy, wt, x.shape, 3, 1, prec=pr, gmax=gm), d0), (cin, cout, H, W, B)
+    sizes, chans = [155, 78, 39, 20], [48, 96, 192, 384]
+    xs = [torch.randn(8, h, h, c, device=dev, generator=g) for c, h in zip(chans, sizes)]
+    ws = [torch.randn(c, 9, c, device=dev, generator=g) * 0.05 for c in chans]
+    y0 = [y.clone() for y in ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=pr)]
+    for _ in range(25):
+        ys = ops.conv_fwd_group(xs, ws, [None] * 4, 3, 1, chans, prec=pr)
+        assert all(torch.equal(a, b) for a, b in zip(ys, y0))
