@@ -1715,17 +1715,20 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     // exec-mask branch per output row and no 64-bit address arithmetic in an epilogue that runs with the matrix pipe idle.
     // (Host-checked: cv_nb * H * W * ld * 4 bytes < 2^31 for y and the residual, conv.hip ws_kind / ws_canvas.)
     const unsigned ldy4 = (unsigned)e_ldy * 4u, ldr4 = (unsigned)e_ldr * 4u;
+    const int wave_rows = pin_i(wave * RPW);               // first tile row of this wave
+    const unsigned g16 = (unsigned)g * 16u;                // this lane's four channels inside a 16-channel tile, bytes
     auto tile_offsets = [&](const Geom& q, unsigned ld4, unsigned (&off)[RPW]) {
-      // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image
+      // this lane's output column: canvas column -> (image, column); invalid on the gap column and past the last image.
+      // One offset per tile (two 32-bit multiplies, quarter rate), the rows of the tile a scalar stride apart.
       const int cxo = q.x0 + r16;
       const int obc = (int)__umulhi((unsigned)cxo, cv_magic);
       const int ox = cxo - obc * cv_w1;
-      const bool ook = (ox < W) & (obc < cv_nb);
+      const bool ook = !(HRSEG_WS_EXP & 32) & (ox < W) & (obc < cv_nb);
+      const int oy0 = q.y0 + wave_rows;
+      const unsigned base = (unsigned)((obc * H + oy0) * W + ox) * ld4 + (unsigned)(q.nt * BN) * 4u + g16;
+      const unsigned rowstep = (unsigned)W * ld4;
 #pragma unroll
-      for (int m = 0; m < RPW; ++m) {
-        const int oy = q.y0 + wave * RPW + m;
-        off[m] = (!(HRSEG_WS_EXP & 32) & ook & (oy < H)) ? (unsigned)((obc * H + oy) * W + ox) * ld4 + (unsigned)(q.nt * BN + 4 * g) * 4u : HRSEG_BUF_OOB;
-      }
+      for (int m = 0; m < RPW; ++m) off[m] = (ook & (oy0 + m < H)) ? base + (unsigned)m * rowstep : HRSEG_BUF_OOB;
     };
     auto fetch_add = [&](const Geom& q) {
 #pragma unroll
@@ -1754,7 +1757,8 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
           for (int n = 0; n < WTN; ++n) add[m][n] += buf_load4(rr, off[m], 64 * n);
       }
     };
-    auto store_acc = [&](const Geom& q) {
+    auto store_acc_as = [&](const Geom& q, auto plain_tag) {
+      constexpr bool PLAIN = decltype(plain_tag)::value;
       const __amdgpu_buffer_rsrc_t ry = make_rsrc(e_y + (size_t)q.b * H * W * e_ldy, (size_t)cv_nb * H * W * ldy4);
       unsigned off[RPW];
       tile_offsets(q, ldy4, off);
@@ -1771,7 +1775,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
           for (int m = 0; m < RPW; ++m) {
             const bool ok = off[m] != HRSEG_BUF_OOB;
-            const f32x4 v = acc[n][m] * oscale + add[m][n];
+            const f32x4 v = PLAIN ? acc[n][m] * oscale : acc[n][m] * oscale + add[m][n];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float ve = ok ? v[e] : 0.f;
@@ -1803,15 +1807,25 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       for (int m = 0; m < RPW; ++m) {
 #pragma unroll
         for (int n = 0; n < WTN; ++n) {
-          f32x4 v = acc[n][m] * oscale + add[m][n];
-          if (e_relu) {
+          f32x4 v = PLAIN ? acc[n][m] * oscale : acc[n][m] * oscale + add[m][n];
+          if (!PLAIN && e_relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           buf_store4(ry, off[m], 64 * n, v);
         }
+        // A 16-byte store reads its data registers over several cycles after it issues, and the compiler lets a packed
+        // multiply of the NEXT row write them in the very next slot (measured on the plain path: the last dword of a row's
+        // last store came out overwritten in the last four lanes of each row of 16, in 0.5 % of the tiles, run to run different).
+        // Nothing crosses this point, and the next vector write is eight wait states away.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
+    // (A specialisation for the training forward -- nothing to add, no ReLU: multiply in place and store -- measured no faster,
+    // and its in-place multiplies are what exposed the store-data hazard above: one code path.)
+    auto store_acc = [&](const Geom& q) { store_acc_as(q, std::false_type{}); };
     bf16x8 xfr[2][RPW][NP], wfr[2][WTN][NP];
     Geom cur = tile_geom(first);
     __syncthreads();                       // the producers' prologue: first patch, weight slabs 0 and 1
