@@ -2125,7 +2125,7 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
             if (!(HRSEG_WS_EXP & 8) && (i + 1 < W_LOADS || wlast)) *reinterpret_cast<f32x4*>(lds + a + i * 4096) = wset[i];
           const unsigned wo = slab_woff(s + 2 + DW);
 #pragma unroll
-          for (int i = 0; i < W_LOADS; ++i) ld16(wset[i], rw, (HRSEG_WS_EXP & 2) ? HRSEG_BUF_OOB : wv[i] + wo, 0u);
+          for (int i = 0; i < W_LOADS; ++i) ld16(wset[i], rw, (HRSEG_WS_EXP & 2) ? HRSEG_BUF_OOB : wv[i], wo);     // (slab offset: scalar)
         }
         // ---- patch of the next stage: the granules loaded at slab s-DP are stored, nl(s) granules are loaded
         if (s >= DP && nl(s - DP) > 0) {
@@ -2428,29 +2428,63 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
   f32x4 rg[LOADS];
   const int pix0 = tid / GPP, gq = tid - pix0 * GPP;
   const bool swork = pix0 < PR;                                // (TNK = 3: all 192 threads; TNK = 4: 12 x 16)
-  auto tile_load = [&](int t) {
-    const int tx = t % p.tiles_x;
-    int r = t / p.tiles_x;
-    const int ty = r % p.tiles_y, b = r / p.tiles_y;
-    const int y0 = ty * 4, x0 = tx * 16;
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
+  // What a thread's granules are does not depend on the tile: their byte offsets from the tile origin (dy) / the patch origin
+  // (x: row y0-1, column x0-1) and their (row, column) there are computed once per block.  A tile that lies inside the image
+  // with its halo loads them with these as the vector offset and the tile origin as the SCALAR offset -- no vector
+  // instruction per granule; a border tile pays two range tests.  (Per tile this was three integer divisions and, per
+  // granule, two quarter-rate 32-bit multiplies: with 1.5 waves per SIMD all of it is paid in MFMA time.)
+  unsigned g_rel[LOADS];
+  int g_yx[LOADS];                                             // (row << 8) | column; a row no image reaches where the granule does not exist
 #pragma unroll
-    for (int i = 0; i < DY_LOADS; ++i) {
+  for (int i = 0; i < LOADS; ++i) {
+    if (i < DY_LOADS) {
       const int pix = pix0 + PR * i;
-      const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
-      const bool ok = swork & (pix < L::DYPIX) & (iy < p.H) & (ix < p.W);
-      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
-      rg[i] = buf_load4(rdy, off, 0);
+      const bool ex = swork & (pix < L::DYPIX);
+      g_rel[i] = ex ? ((unsigned)((pix >> 4) * p.W + (pix & 15)) * (unsigned)p.lddy + (unsigned)(n0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+      g_yx[i] = ex ? ((pix >> 4) << 8) | (pix & 15) : 0x400000;
+    } else {
+      const int pix = pix0 + PR * (i - DY_LOADS);
+      const int py = (pix * 3641) >> 16, px = pix - py * 18;         // pix / 18
+      const bool ex = swork & (pix < L::XPIX);
+      g_rel[i] = ex ? ((unsigned)(py * p.W + px) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
+      g_yx[i] = ex ? (py << 8) | px : 0x400000;
     }
+  }
+  // tile cursor of the NEXT load (tiles walk columns, rows, images): one division per block
+  int c_tx = t_lo % p.tiles_x, c_ty = (t_lo / p.tiles_x) % p.tiles_y, c_b = (t_lo / p.tiles_x) / p.tiles_y;
+  c_tx = __builtin_amdgcn_readfirstlane(c_tx); c_ty = __builtin_amdgcn_readfirstlane(c_ty); c_b = __builtin_amdgcn_readfirstlane(c_b);
+  const unsigned lddy4 = (unsigned)p.lddy * 4u, ldx4 = (unsigned)p.ldx * 4u;
+  auto tile_load = [&]() {
+    const int y0 = c_ty * 4, x0 = c_tx * 16;
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)c_b * p.H * p.W * p.lddy, (size_t)p.H * p.W * p.lddy * 4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)c_b * p.H * p.W * p.ldx, (size_t)p.H * p.W * p.ldx * 4);
+    const unsigned dyb = (unsigned)(y0 * p.W + x0) * lddy4;
+    const unsigned xb = (unsigned)((y0 - 1) * p.W + x0 - 1) * ldx4;          // (mod 2^32 on a border tile: only added to offsets that exist)
+    const bool dy_full = (y0 + 4 <= p.H) & (x0 + 16 <= p.W);
+    const bool x_full = (y0 >= 1) & (x0 >= 1) & (y0 + 5 <= p.H) & (x0 + 17 <= p.W);
+    if (dy_full) {
 #pragma unroll
-    for (int i = 0; i < X_LOADS; ++i) {
-      const int pix = pix0 + PR * i;
-      const int py = (pix * 3641) >> 16, px = pix - py * 18;           // pix / 18
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = swork & (pix < L::XPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.ldx + (unsigned)(k0 + 4 * gq)) * 4u : HRSEG_BUF_OOB;
-      rg[DY_LOADS + i] = buf_load4(rx, off, 0);
+      for (int i = 0; i < DY_LOADS; ++i) rg[i] = buf_load4(rdy, g_rel[i], (int)dyb);
+    } else {
+#pragma unroll
+      for (int i = 0; i < DY_LOADS; ++i) {
+        const bool ok = (y0 + (g_yx[i] >> 8) < p.H) & (x0 + (g_yx[i] & 255) < p.W);
+        rg[i] = buf_load4(rdy, ok ? g_rel[i] + dyb : HRSEG_BUF_OOB, 0);
+      }
+    }
+    if (x_full) {
+#pragma unroll
+      for (int i = DY_LOADS; i < LOADS; ++i) rg[i] = buf_load4(rx, g_rel[i], (int)xb);
+    } else {
+#pragma unroll
+      for (int i = DY_LOADS; i < LOADS; ++i) {
+        const bool ok = ((unsigned)(y0 - 1 + (g_yx[i] >> 8)) < (unsigned)p.H) & ((unsigned)(x0 - 1 + (g_yx[i] & 255)) < (unsigned)p.W);
+        rg[i] = buf_load4(rx, ok ? g_rel[i] + xb : HRSEG_BUF_OOB, 0);
+      }
+    }
+    if (++c_tx == p.tiles_x) {
+      c_tx = 0;
+      if (++c_ty == p.tiles_y) { c_ty = 0; ++c_b; }
     }
   };
   auto tile_store = [&]() {
@@ -2488,11 +2522,11 @@ __device__ __forceinline__ void wgrad9_sp_body(const Wgrad9Args& p, unsigned cha
   const int dy_lane = (4 * g + lrow) * S + lcol;                              // + (2ks+h)*16*S + n*32
   const int x_lane = XBASE + (kh * 18 + 4 * g + lrow) * S + lcol;             // + ((2ks+h)*18 + kw)*S + k*32
 
-  if (t_lo < t_hi) tile_load(t_lo);
+  if (t_lo < t_hi) tile_load();
   for (int t = t_lo; t < t_hi; ++t) {
     __syncthreads();                         // every wave is done with the previous tile's images
     tile_store();
-    if (t + 1 < t_hi) tile_load(t + 1);      // in flight behind this tile's MFMAs
+    if (t + 1 < t_hi) tile_load();           // in flight behind this tile's MFMAs
     __syncthreads();
     // Six groups (pixel half ks, kernel column kw) of TNK x TNK tiles.  Inside a group the products go output-channel
     // block k outermost, so the x fragments of block k are dead after its TNK * products MFMAs and the reads of the

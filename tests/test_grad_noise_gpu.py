@@ -48,6 +48,22 @@ def test_gpu_gradients_are_as_close_to_fp64_as_the_fp32_reference(name, mode):
                               level_weights=w, level0_pretrain_epochs=None, batch_size=batch)
     pm = build_model(PM, kind, hier, tree, size).cuda()
     pm.train()
+    # Deterministic mode: the claim is about OPERAND precision.  With atomics on, the summation order of the 64-pixel HRNet's
+    # 2 x 2-pixel branch (BatchNorm over 8 samples) moves the result between two basins from run to run -- median 5.5e-3 or
+    # 2.0e-2, worst parameter 0.15 or 0.24, whatever the kernels (measured round 4, three runs each at two nine-tap block
+    # plans) -- which says nothing about 22-bit operands; the deterministic evaluation is the same every run (1.45e-3 / 9.6e-3).
+    from hrseg_amd import _lib
+    _lib.set_deterministic(True)
+    try:
+        e_gpu, e_cpu = _errors(pm, mode, x, t, args, tree, hier, w, g64, g32)
+    finally:
+        _lib.set_deterministic(False)
+    _check(name, mode, e_gpu, e_cpu)
+
+
+def _errors(pm, mode, x, t, args, tree, hier, w, g64, g32):
+    from hrseg_amd.Metrics import losses as PL
+    from hrseg_amd import train as PT
     with conv_mode(pm, mode):
         probs, logits = PT._model_call(pm, x.cuda(), args, tree)
         logits = logits if hier else [logits]
@@ -65,7 +81,10 @@ def test_gpu_gradients_are_as_close_to_fp64_as_the_fp32_reference(name, mode):
             continue
         e_cpu.append(np.abs(g32[n] - ref).max() / s)
         e_gpu.append(np.abs(p.grad.cpu().double().numpy() - ref).max() / s)
-    e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
+    return np.array(e_gpu), np.array(e_cpu)
+
+
+def _check(name, mode, e_gpu, e_cpu):
     assert len(e_gpu) > 20
     print(f"{name} {mode}: median err gpu {np.median(e_gpu):.2e} cpu32 {np.median(e_cpu):.2e}; max gpu {e_gpu.max():.2e} cpu32 {e_cpu.max():.2e}")
     # Default routing (`auto`: at these sizes the exact-fp32 MFMA kernels, fp16x2 weight gradients): the GPU path is as far from
@@ -77,7 +96,8 @@ def test_gpu_gradients_are_as_close_to_fp64_as_the_fp32_reference(name, mode):
     # the reference; UNet shows no difference (2.3e-3).  That is the price of 22-bit operands on ill-conditioned small layers and
     # the reason the default policy keeps problems under 8192 pixels on the exact-fp32 kernels; at the headline size the
     # fp16x2 kernels run only on the large layers (test_train_steps_track_the_oracle_at_256 pins that routing).
-    f_med, f_p90, f_max = (1.5, 2.0, 3.0) if mode == "auto" else (5.0, 6.0, 12.0)
+    # (deterministic evaluation, round 4: auto 0.31x / 0.60x of the reference at the median / maximum; auto_ws 2.0x / 4.2x)
+    f_med, f_p90, f_max = (1.5, 2.0, 3.0) if mode == "auto" else (3.0, 6.0, 6.0)
     assert np.median(e_gpu) <= f_med * np.median(e_cpu) + 1e-6
     assert np.percentile(e_gpu, 90) <= f_p90 * np.percentile(e_cpu, 90) + 1e-6
     assert e_gpu.max() <= f_max * e_cpu.max() + 1e-5
