@@ -259,6 +259,9 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
   constexpr int D = SP_DEPTH;
   int u_next = 2 * s_lo;
   const int u_end = min(nunits, 2 * s_hi);
+  // (tap, chunk) of unit u_next, stepped unit by unit: ONE division per block (a division per unit is ~25 vector instructions
+  // twice per slab, in a body whose slab is 6-36 MFMAs)
+  int u_t = __builtin_amdgcn_readfirstlane(u_next / kch), u_c = u_next - u_t * kch;
   f32x4 ra[D][WTM][2], rwt[D][W_LOADS];
   auto issue_loads = [&](f32x4 (&ra)[WTM][2], f32x4 (&rwt)[W_LOADS]) {
     unsigned soff[2], wsoff[2];
@@ -267,8 +270,9 @@ __device__ __forceinline__ void igemm_sp_body(const IgemmArgs& p, unsigned char*
     for (int h = 0; h < 2; ++h) {
       const int u = u_next + h;
       const bool live = u < u_end;
-      const int t = live ? u / kch : 0;
-      const int c = u - t * kch;
+      const int t = live ? u_t : 0;
+      const int c = live ? u_c : 0;
+      if (++u_c == kch) { u_c = 0; ++u_t; }
       const int dy = (int)((p.offy_pk >> (4 * t)) & 15) - 8 - p.oy_min, dx = (int)((p.offx_pk >> (4 * t)) & 15) - 8 - p.ox_min;
       soff[h] = (unsigned)((dy * p.Wi + dx) * p.ldx + 16 * c) * 4u;
       wsoff[h] = live ? (unsigned)((int)((p.wtap_pk >> (4 * t)) & 15) * p.K + 16 * c) * 4u : HRSEG_BUF_OOB;
@@ -526,6 +530,7 @@ __device__ __forceinline__ void igemm_spw_body(const IgemmArgs& p, unsigned char
   const int u_end = min(nunits, 2 * s_hi);
   unsigned w_off = (unsigned)(nt * nslabs_all + s_lo) * (unsigned)WSTAGE;        // image offset of the next slab to load
   const unsigned w_end = (unsigned)(nt * nslabs_all + s_hi) * (unsigned)WSTAGE;
+  int u_t = __builtin_amdgcn_readfirstlane(u_next / kch), u_c = u_next - u_t * kch;      // (tap, chunk) of unit u_next, stepped (igemm_sp_body)
   f32x4 ra[D][WTM][2], rwt[D][W_LOADS];
   auto issue_loads = [&](f32x4 (&ra)[WTM][2], f32x4 (&rwt)[W_LOADS]) {
     unsigned soff[2];
@@ -534,8 +539,9 @@ __device__ __forceinline__ void igemm_spw_body(const IgemmArgs& p, unsigned char
     for (int h = 0; h < 2; ++h) {
       const int u = u_next + h;
       const bool live = u < u_end;
-      const int t = live ? u / kch : 0;
-      const int c = u - t * kch;
+      const int t = live ? u_t : 0;
+      const int c = live ? u_c : 0;
+      if (++u_c == kch) { u_c = 0; ++u_t; }
       const int dy = (int)((p.offy_pk >> (4 * t)) & 15) - 8 - p.oy_min, dx = (int)((p.offx_pk >> (4 * t)) & 15) - 8 - p.ox_min;
       soff[h] = live ? (unsigned)((dy * p.Wi + dx) * p.ldx + 16 * c) * 4u : 0u;
       tapbit[h] = live ? t : 31;
