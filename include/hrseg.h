@@ -163,7 +163,7 @@ long hrseg_launch_count(const char* family, int reset);
  * block-synchronous kernels), sp_ws_waste (accepted tile padding, percent), sp_ws_bf16 (0: the BF16 arithmetic stays off the wave-specialised kernels), small_cin3 (0: the 3-channel first layer on the generic
  * Cin <= 8 kernels), sp_ws_canvas (0: tile every image on its own, never the batch as one
  * canvas), sp_img (0: block-synchronous kernels
- * split their weights on the fly); wgrad9 (0: never the nine-tap weight gradient), wgrad9_blocks (its target block count); wgrad_group_sp (0: grouped tap-per-block
+ * split their weights on the fly); wgrad9 (0: never the nine-tap weight gradient), wgrad9_blocks (its target block count per problem; wgrad9_blocks1 .. wgrad9_blocks4: the same for launches of 1 .. 4 problems); wgrad_group_sp (0: grouped tap-per-block
  * weight gradients stay on the fp32 kernel), wgrad_sp_t5 (0: no 80 x 80 tiles for the wide layers), wgrad_sp_wide (0: never the wide-tile weight-gradient body); deterministic (1: single-adder
  * reductions everywhere); routing thresholds sp_ws_min_tiles (96), auto_min_pixels (8192), sp_patch_min_tiles (192): the
  * parity tests lower them so that small cases run the kernels of the headline sizes -- csrc/conv.hip, hrseg_tune.  Unknown key: HRSEG_ERR_INVALID_ARG. */
