@@ -76,6 +76,17 @@ class conv_mode:
         self.model.conv_dtype = {"auto_ws": "auto"}.get(self.mode, self.mode)
         if self.mode in ("fp16x2", "auto_ws"):
             _lib.tune(sp_ws_min_tiles=1, sp_patch_min_tiles=1, auto_min_pixels=1)
+        # The 64-pixel HRNet ends in a 2 x 2-pixel branch whose BatchNorm normalises over 8 samples: with EVERY contraction forced
+        # onto 22-bit operands its backward is chaotic, and with atomics on the summation order moves the gradients between two
+        # basins ~1e-2 apart from run to run (tests/test_grad_noise_gpu.py; round 4 measured it on five library builds: the same
+        # four cases 4/4, 3/4 or 1/4 green depending on nothing but kernel timing, 4/4 in deterministic mode on every build).
+        # These cases compare KERNEL arithmetic with the reference, so they evaluate in deterministic mode; the default mode
+        # (atomics, statistics in the conv epilogue) is what the UNet cases of the same modes, `auto`, the 256- and 620-pixel
+        # tests and tests/test_tape_gpu.py run.
+        self.det = (self.mode in ("fp16x2", "auto_ws") and type(self.model).__name__ == "HighResolutionNet"
+                    and not _lib.deterministic())
+        if self.det:
+            _lib.set_deterministic(True)
         _lib.launch_count(None, reset=True)
         return self
 
@@ -85,6 +96,8 @@ class conv_mode:
                     "wgrad_f32", "wgrad_f32_group", "wgrad9", "wgrad_sp_group"):
             self.counts[fam] = _lib.launch_count(fam, reset=True)
         _lib.tune(sp_ws_min_tiles=0, sp_patch_min_tiles=0, auto_min_pixels=0)      # 0 = defaults
+        if self.det:
+            _lib.set_deterministic(False)
         return False
 
     def check_families(self, kind):
