@@ -1537,20 +1537,10 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   constexpr int P_LOADS = (PP + PR - 1) / PR;              // rounds per K stage
   constexpr int W16 = L::WSTAGE / 16, W_LOADS = (W16 + 255) / 256;     // 16-byte granules of a pre-split weight slab
   constexpr int NU = 9 * CS, NSLAB = (NU + 1) / 2;
-#ifndef HRSEG_WS_PRODUCER
-#define HRSEG_WS_PRODUCER 1  // 0: the round-3 producer (one flat loop over slabs), kept for A/B builds
-#endif
 #ifndef HRSEG_WS_EXP
 #define HRSEG_WS_EXP 0       // MEASUREMENT ONLY (wrong results): 1 no MFMAs, 2 no weight loads, 4 no patch loads, 8 no weight stores, 16 no epilogue, 32 epilogue stores out of range
 #endif
-#ifndef HRSEG_WS_LOOKAHEAD
-#define HRSEG_WS_LOOKAHEAD 4
-#endif
-  constexpr int D = HRSEG_WS_LOOKAHEAD;                    // producer look-ahead, slabs (a power of two)
   static_assert(NSLAB % 2 == 0, "register-set parity must restart with every K stage");
-  constexpr int GPS = (P_LOADS + NSLAB - 2 - D) / (NSLAB - 1 - D);     // patch granules per thread and slab
-  constexpr int P_SLABS = (P_LOADS + GPS - 1) / GPS;                   // slabs of a stage that stage patch granules
-  static_assert(P_SLABS + D <= NSLAB - 1, "the next K stage's patch is complete one slab before the stage ends");
   unsigned char* lpatch = lds;                             // [2][PATCH]
   unsigned char* lw = lds + 2 * L::PATCH;                  // [3][WSTAGE]
   // BatchNorm statistics of the OUTPUT in the epilogue (p.stat_partial, training forward): the block keeps [2][N] fp64 sums
@@ -1576,7 +1566,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
   const int ntn = p.N / BN;
   const int nks = p.K / (16 * CS);
   if (first >= end) return;
-  const int total = (end - first) * nks * NSLAB;           // slabs of this block
 #ifndef HRSEG_WS_STAMP
 #define HRSEG_WS_STAMP 0     // MEASUREMENT ONLY: block 0's waves 0 (consumer) and 4 (producer) write the time they ARRIVE at every slab barrier
 #endif                       // and the time they LEAVE it into p.stat_partial ([role][slab][2] 64-bit counters; no statistics then)
@@ -1640,10 +1629,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
     constexpr int NP = sp_np(NS);
     constexpr int UNITS = RPW * NP + WTN * NP;             // fragment registers (8 halfs each) of a slab
     constexpr int MM = WTN * RPW * sp_nprod(NS);           // MFMAs of a slab
-#ifndef HRSEG_WS_READ_LAG
-#define HRSEG_WS_READ_LAG 0
-#endif
-    constexpr int MR = MM > 2 * HRSEG_WS_READ_LAG ? MM - HRSEG_WS_READ_LAG : MM;     // MFMAs that carry the next slab's reads
     // fragment r of slab `slab` (compile-time) -> register set
     // A pixel fragment's LDS address is (patch pixel prow0 + c) * 32 + the 8-byte slot g, swizzled by bit 3 of the pixel index,
     // c = m * PW + tap offset a compile-time constant.  The swizzle depends on c only through c mod 16, so SIXTEEN per-lane base
@@ -1870,10 +1855,10 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
                 } else {
                   acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s & 1][n][0], xfr[s & 1][m][0], acc[n][m], 0, 0, 0);
                 }
-                // the next slab's reads go out behind the slab's first MR MFMAs: the last HRSEG_WS_READ_LAG MFMAs cover their
-                // latency, so that the wait before the slab barrier finds them complete
+                // the next slab's fragment reads, spread over this slab's MFMAs (front-loading them so that the last MFMAs cover
+                // their latency measured no different: the wait before the slab barrier is not where the slab's time goes)
 #pragma unroll
-                for (int r = (k < MR ? k : MR) * UNITS / MR; r < (k + 1 < MR ? k + 1 : MR) * UNITS / MR; ++r)
+                for (int r = k * UNITS / MM; r < (k + 1) * UNITS / MM; ++r)
                   read_unit(nslab, wb1, r, xfr[(s + 1) & 1], wfr[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 ++k;
@@ -1907,9 +1892,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
       if (!have_next) break;
     }
-#if !HRSEG_WS_PRODUCER
-    for (int k = total; k & (D - 1); ++k) __builtin_amdgcn_s_barrier();      // the producers' loop is unrolled by D slabs
-#endif
     if (SREG && e_sreg) {          // the register sums of this wave: row reduction, then one fp64 LDS atomic per channel and sum
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
@@ -1924,7 +1906,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       }
     }
   } else {
-#if HRSEG_WS_PRODUCER
     // PRODUCERS.  A wave issues an instruction every four or five cycles at best and the block meets at ONE barrier per slab, so a
     // slab lasts as long as its slowest wave's instruction stream: a 36-MFMA slab is 576 cycles of the matrix pipe, i.e. ~120
     // producer instructions.  (Round 4 measured the previous flat-loop producer -- ~230 instructions per slab on the 16-row
@@ -2165,171 +2146,6 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
       advance();
     } while (++q < nstages);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead loads of slabs past the block's last
-#else
-
-    // Producers run a flat loop over the block's slabs (j = 0 .. total-1, indices runtime and wave-uniform): at slab j
-    // they store weight slab j+2 (loaded four slabs earlier into register set (j+2)%4) and issue the loads of slab
-    // j+6 into the same set; the next K stage's patch goes granule by granule, loaded at in-stage slab s and stored
-    // at s+4.  The loads and their waits are written by hand: with conditional stores in the loop the compiler's
-    // waitcnt pass falls back to vmcnt(0) before every use, i.e. one slab of look-ahead (measured: the producers then
-    // take 2.5x the consumers' time).  Every slab issues exactly W_LOADS weight loads and then GPS patch loads, valid
-    // or not (out-of-range offsets cost no traffic), so the number of younger loads behind any load is a constant
-    // and `s_waitcnt vmcnt(constant)` waits for exactly the loads a store needs.
-    float xscale, xinv;
-    sp_pow2_scale(p.xmax, xscale, xinv);
-    const int per_tile = nks * NSLAB;                      // slabs (= weight image entries) per tile
-    auto rsrc_words = [](const void* base, size_t bytes) {
-      const unsigned long long a = (unsigned long long)base;
-      i32x4_t r;
-      r[0] = (int)(unsigned)(a & 0xffffffffull);
-      r[1] = (int)(unsigned)((a >> 32) & 0xffffull);
-      r[2] = (int)(unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes);
-      r[3] = HRSEG_BUF_FLAGS;
-      return r;
-    };
-    auto ld16 = [](f32x4& dst, const i32x4_t& rs, unsigned voff, int soff) {
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-    };
-    const i32x4_t rw = rsrc_words(p.wimg, (size_t)ntn * per_tile * L::WSTAGE);
-    constexpr int PER_SLAB = W_LOADS + GPS;                // loads issued per slab, in this order: weights, patch
-    constexpr int WAIT_W = GPS + (D - 1) * PER_SLAB;       // loads younger than a weight set at the slab that stores it
-    constexpr int WAIT_P = (D - 1) * PER_SLAB + W_LOADS;   // ... than the last patch granule of a slab, ditto
-    static_assert(WAIT_W < 64 && WAIT_P < 64, "vmcnt is a 6-bit counter");
-    const int pix0 = ptid / GPP, prem = ptid - pix0 * GPP;
-    const bool pwork = pix0 < PR;                          // (CS = 3: the last four threads stage no patch granule)
-    const unsigned prem16 = (unsigned)prem * 16u;
-    const int pst0 = (prem >> 2) * L::CHUNK, pq = prem & 3;
-    const unsigned ldx4 = (unsigned)p.ldx * 4u;
-    // descriptor of the image the patch comes from (rebuilt when the stage cursor moves to another image)
-    auto image_rsrc = [&](int b) { return rsrc_words(p.x + (size_t)b * H * W * p.ldx, (size_t)cv_nb * H * W * p.ldx * 4); };
-    auto patch_load1 = [&](f32x4& dst, const i32x4_t& rx, const Geom& q, int ks, int i, bool valid) {
-      const int pix = pix0 + PR * i;
-      const int py = (pix * 3641) >> 16, px = pix - py * PW;           // pix / 18 for pix < 2^12
-      const int iy = q.y0 - 1 + py, cx = q.x0 - 1 + px;
-      const int bc = (int)__umulhi((unsigned)cx, cv_magic);             // image on the canvas (0 in plain mode)
-      const int ix = cx - bc * cv_w1;
-      const bool ok = !(HRSEG_WS_EXP & 4) & valid & pwork & (pix < PP) & ((unsigned)iy < (unsigned)H) & (cx >= 0) & (ix < W) & (bc < cv_nb);
-      const unsigned off = ok ? (unsigned)((bc * H + iy) * W + ix) * ldx4 + prem16 : HRSEG_BUF_OOB;
-      ld16(dst, rx, off, ks * CS * 64);
-    };
-    const int exp_nosplit = p.exp_nosplit | p.x_presplit;        // x stored pre-split: copy, do not split (see hrseg.h x_split)
-    auto patch_store1 = [&](const f32x4& v, int i, int pbuf) {
-      u32x2 pc[sp_np(NS)];
-      if (exp_nosplit) {                           // MEASUREMENT ONLY (hrseg_tune exp_nosplit_x; wrong values on purpose)
-        const u32x4 raw = __builtin_bit_cast(u32x4, v);
-#pragma unroll
-        for (int s = 0; s < sp_np(NS); ++s) pc[s] = u32x2{raw[(2 * s) & 3], raw[(2 * s + 1) & 3]};
-      } else {
-        sp_split4<NS>(v, pc, xscale);
-      }
-      const int pix = pix0 + PR * i;
-      const int o = pbuf * L::PATCH + pst0 + pix * 32 + ((pq ^ (2 * ((pix >> 3) & 1))) << 3);
-      if (pwork & (pix < PP)) {
-#pragma unroll
-        for (int s = 0; s < sp_np(NS); ++s) *reinterpret_cast<u32x2*>(lpatch + s * L::PPIECE + o) = pc[s];
-      }
-    };
-    f32x4 rw4[D][W_LOADS], rpg[D][GPS];
-    Geom cur = tile_geom(first);
-    int l_t = first, l_j = 0, l_nt = cur.nt;               // weight-load cursor: tile, slab within the tile, channel tile
-    unsigned l_off = (unsigned)(l_nt * per_tile) * (unsigned)L::WSTAGE;
-    auto w_issue = [&](f32x4 (&set)[W_LOADS]) {
-#pragma unroll
-      for (int i = 0; i < W_LOADS; ++i) {
-        const int f = ptid + 256 * i;
-#if HRSEG_WS_EXP & 2
-        ld16(set[i], rw, HRSEG_BUF_OOB, 0);
-#else
-        ld16(set[i], rw, (f < W16 && l_t < end) ? l_off + (unsigned)f * 16u : HRSEG_BUF_OOB, 0);
-#endif
-      }
-      l_off += L::WSTAGE;
-      if (++l_j == per_tile) {
-        l_j = 0;
-        ++l_t;
-        if (++l_nt == ntn) { l_nt = 0; l_off = 0; }       // the image is channel tile after channel tile
-      }
-    };
-    auto w_put = [&](int wboff, const f32x4 (&set)[W_LOADS]) {
-#pragma unroll
-      for (int i = 0; i < W_LOADS; ++i) {
-        const int f = ptid + 256 * i;
-        if (f < W16) *reinterpret_cast<f32x4*>(lw + wboff + f * 16) = set[i];
-      }
-    };
-    // prologue: the first patch (loads waited for one by one), weight slabs 0 and 1 into LDS, then slabs 2..5 in
-    // flight with the steady-state pattern (each followed by GPS patch loads, dummies here)
-    {
-      // all loads of the first patch and of weight slabs 0 and 1 in flight together: one L2 round trip, not one per granule
-      f32x4 v[P_LOADS];
-      const i32x4_t rx0 = image_rsrc(cur.b);
-#pragma unroll
-      for (int i = 0; i < P_LOADS; ++i) patch_load1(v[i], rx0, cur, 0, i, true);
-      w_issue(rw4[0]);
-      w_issue(rw4[1]);
-#pragma unroll
-      for (int i = 0; i < P_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]));
-#pragma unroll
-      for (int i = 0; i < P_LOADS; ++i) patch_store1(v[i], i, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw4[0][i]), "+v"(rw4[1][i]));
-    w_put(0, rw4[0]);
-    w_put(L::WSTAGE, rw4[1]);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      w_issue(rw4[(d + 2) % D]);
-#pragma unroll
-      for (int e = 0; e < GPS; ++e) patch_load1(rpg[(d + 2) % D][e], rw, cur, 0, 0, false);
-    }
-    __syncthreads();
-    int wb2 = 2 * L::WSTAGE;               // weight buffer of slab j+2
-    int s = 0, pb = 0;                     // in-stage slab of j, patch buffer of the current stage
-    int n_t = first, n_ks = 0;             // the stage after the current one
-    bool have_next = false;
-    Geom nxt = cur;
-    i32x4_t rxn = image_rsrc(cur.b);
-    auto stage_begin = [&]() {
-      if (++n_ks == nks) {
-        n_ks = 0;
-        ++n_t;
-        const int b = nxt.b;
-        tile_next(nxt);
-        if (nxt.b != b) rxn = image_rsrc(nxt.b);
-      }
-      have_next = n_t < end;
-    };
-    stage_begin();
-    for (int j = 0; j < total; j += D) {
-#pragma unroll
-      for (int u = 0; u < D; ++u) {
-        // (the slab count is padded to a multiple of D; the consumers meet the padding's barriers too)
-        f32x4 (&wset)[W_LOADS] = rw4[(u + 2) % D];
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wset[i]) : "n"(WAIT_W));
-        if (!(HRSEG_WS_EXP & 8) && j + u + 2 < total) w_put(wb2, wset);
-        w_issue(wset);
-        // rpg[(u+2)%D] holds the granules loaded four slabs ago (the prologue's dummies shift the ring by two)
-        f32x4 (&pset)[GPS] = rpg[(u + 2) % D];
-#pragma unroll
-        for (int e = 0; e < GPS; ++e) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pset[e]) : "n"(WAIT_P));
-#pragma unroll
-        for (int e = 0; e < GPS; ++e) {
-          const int ist = (s - D) * GPS + e;
-          if (have_next && s >= D && ist < P_LOADS) patch_store1(pset[e], ist, pb ^ 1);
-        }
-#pragma unroll
-        for (int e = 0; e < GPS; ++e) {
-          const int ild = s * GPS + e;
-          patch_load1(pset[e], rxn, nxt, n_ks, ild, have_next && ild < P_LOADS);
-        }
-        __syncthreads();
-        wb2 = (wb2 == 2 * L::WSTAGE) ? 0 : wb2 + L::WSTAGE;
-        if (++s == NSLAB) { s = 0; pb ^= 1; stage_begin(); }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummies before the wave ends
-#endif
   }
   if (stat) {
     // every consumer has added its last tile (LDS atomics complete before the barrier); the block's sums go out as row
