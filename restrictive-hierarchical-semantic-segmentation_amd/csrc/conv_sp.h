@@ -1403,13 +1403,14 @@ void igemm_patch_sp_kernel(IgemmArgs p, int ntotal) {
 // 0.30-0.34).  Here a 512-thread block splits the roles.  Waves 0-3 (one per SIMD) are CONSUMERS: per slab they issue
 // the MFMAs of the current slab in an order that never puts two dependent products back to back, with the LDS reads
 // of the NEXT slab's fragments pinned between them (sched_barrier keeps the compiler from sinking the reads to their
-// uses), and nothing else.  Waves 4-7 are PRODUCERS: a wave issues one instruction every four cycles at best, so the
-// producer has ~140 issue slots per 36-MFMA slab; splitting the weight slab on the fly (18 VALU per 16-byte granule,
-// three granules per thread) does not fit, splitting it once does: the weights come PRE-SPLIT from a global image
-// laid out slab by slab exactly like the LDS buffer (sp_weight_image_kernel, one small launch per convolution) and
-// the producers only copy them -- global -> registers four slabs ahead -> ds_write_b128 two slabs ahead -- and stage
-// the next K stage's patch into the second patch buffer, one granule per slab.  One barrier per slab orders both
-// roles.  One block per CU, persistent over a range of tiles.
+// uses), and nothing else.  Waves 4-7 are PRODUCERS.  The roles share their SIMD's vector issue: an MFMA leaves 8 of its 16
+// cycles free, and every vector / LDS / memory instruction of EITHER wave beyond that is paid in matrix-pipe time (measured,
+// DESIGN.md section 3) -- the split of roles moves the staging instructions, it does not make them free, so the producer is
+// written for instruction count: the weights come PRE-SPLIT from a global image laid out slab by slab exactly like the LDS
+// buffer (splitting a weight slab on the fly is ~30 instructions per thread and slab; the image is persistent, rebuilt once
+// per model call) and the producers only copy them -- global -> registers two slabs ahead -> ds_write_b128 two slabs ahead of
+// their first read -- and stage the next K stage's patch into the second patch buffer from per-block granule tables.  One
+// barrier per slab orders both roles.  One block per CU, persistent over a range of tiles.
 template <int NS, int TH, int WTN, int CS>
 struct SpPatchWsLds {
   using P = SpPatchLds<NS, TH, WTN, CS>;
@@ -1721,7 +1722,15 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #pragma unroll
       for (int m = 0; m < RPW; ++m) off[m] = (ook & (oy0 + m < H)) ? base + (unsigned)m * rowstep : HRSEG_BUF_OOB;
     };
+    const int e_nothing = pin_i((!p.bias && !p.accumulate && !p.res) ? 1 : 0);
     auto fetch_add = [&](const Geom& q) {
+      if (e_nothing) {             // the training forward and the plain data gradient: zeros, behind ONE scalar branch (the general
+#pragma unroll                    // path below spent ~700 cycles per tile on its three not-taken cases: tools/ws_stamps.py)
+        for (int m = 0; m < RPW; ++m)
+#pragma unroll
+          for (int n = 0; n < WTN; ++n) add[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+      }
 #pragma unroll
       for (int n = 0; n < WTN; ++n) {
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1873,9 +1882,24 @@ __device__ __forceinline__ void igemm_patch_ws_body(const IgemmArgs& p, unsigned
 #else
           if (PF && s == S_PF && last_ks && e_early) fetch_add(cur);
           if (s == NSLAB - 1 && last_ks) {
+#if HRSEG_WS_STAMP
+            unsigned long long e0, e1, e2, e3;                // (measurement build: the epilogue's phases of wave 0, block 0)
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0) :: "memory");
+            if (!(PF && e_early)) fetch_add(cur);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1) :: "memory");
+            store_acc(cur);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e2) :: "memory");
+            zero_acc();
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e3) :: "memory");
+            if (stamping && wave == 0 && lane == 0 && stamp_j < 1024) {
+              unsigned long long* o = stamp_out + 4096 + stamp_j * 4;
+              o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3;
+            }
+#else
             if (!(PF && e_early)) fetch_add(cur);
             store_acc(cur);
             zero_acc();
+#endif
           }
 #endif
           // The slab barrier orders LDS traffic only (the producers' ds_writes against these reads).  __syncthreads() would

@@ -10,6 +10,9 @@ import torch
 
 from hrseg_amd import _lib, ops
 
+import ctypes
+
+ops._stat_buffer = lambda cout, device: (torch.zeros(ops.STAT_ROWS_MAX * 2 * cout, dtype=torch.float64, device=device), ctypes.c_int(0))   # (stamps land in zeros)
 dev = torch.device("cuda:0")
 pr = _lib.CONV_PRECISION["auto"]
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -33,5 +36,10 @@ for c, h, b, nsl in [(48, 155, 64, 14), (96, 78, 128, 14), (384, 78, 32, 14), (6
     for j in range(0, min(len(cb), 5 * nsl)):
         tag = " <- tile/stage end" if (j + 2) % nsl == 0 else ""
         print("  slab %3d: C %5d %5d | P %5d %5d%s" % (j + 1, cb[j], cw[j], pb[j], pw[j], tag))
+    ep = part.view(torch.int64).reshape(-1)[4096 * 1 : 4096 + 1024 * 4].cpu().numpy().reshape(1024, 4)
+    ep = ep[(ep[:, 0] > 0) & (ep[:, 3] > ep[:, 0])][1:6]
+    for e in ep:
+        print("  epilogue of a tile: values to add %5d | scale, (statistics,) stores %5d | zero the accumulators %5d cycles" % (
+            e[1] - e[0], e[2] - e[1], e[3] - e[2]))
     print("  mean over %d slabs: consumer busy %.0f wait %.0f | producer busy %.0f wait %.0f | slab %.0f" % (
         len(cb), cb.mean(), cw.mean(), pb.mean(), pw.mean(), (cl[-1] - cl[0]) / (len(cl) - 1)))
